@@ -1,0 +1,109 @@
+/* mmrag.h -- C-ABI of the MI355X-native embed-and-retrieve engine (libmmrag.so).
+ *
+ * Drop-in boundary for the hot path of someone-in-somewhere/multimodal_rag
+ * (app/utils/embedder.py).  The reference has no FFI of its own: its arithmetic lives in
+ * two third-party engines that embedder.py calls through Python.  Each entry point below
+ * replaces one of those engine calls; INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add at the cited call site.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `dev` pointer is HIP device memory owned by the
+ *     caller (in this repo: torch tensors' data_ptr()); nothing is retained past return;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued on it and the call returns without synchronising;
+ *   - return value: 0 = ok, otherwise an MMRAG_E* code; mmrag_last_error() gives the
+ *     message for the calling thread.  No entry point aborts or throws;
+ *   - re-entrant: no global mutable scratch; callers pass a workspace sized by the matching
+ *     *_workspace_bytes() query (embedder.py:368/595 call the engines from thread-pool
+ *     workers, SURVEY.md section 8b "Threading").
+ *
+ * There is NO CPU fallback behind these symbols: without a gfx950 device they fail.
+ */
+#ifndef MMRAG_H
+#define MMRAG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMRAG_OK 0
+#define MMRAG_EINVAL 1   /* bad argument (shape, alignment, dtype, k) */
+#define MMRAG_EWORKSPACE 2 /* workspace too small */
+#define MMRAG_EHIP 3     /* a HIP runtime call failed */
+#define MMRAG_EUNSUPPORTED 4
+
+/* storage dtype of vectors / weights / activations */
+#define MMRAG_F32 0
+#define MMRAG_F16 1
+#define MMRAG_BF16 2
+
+#define MMRAG_MAX_K 20 /* api.py:163  top_k: int = Field(5, ge=1, le=20) */
+
+int mmrag_abi_version(void);
+const char *mmrag_last_error(void);
+
+/* Leading dimension (in elements) the corpus / query matrices must be padded to for `d`
+ * logical columns of `dtype`: rows are streamed in 128-byte K-slabs.  Pad columns are 0. */
+int64_t mmrag_padded_dim(int d, int dtype);
+
+/* ---------------------------------------------------------------------------------------
+ * Retrieve.  Replaces chromadb's  collection.query(query_embeddings=[v], n_results=k, ...)
+ * reference call site: app/utils/embedder.py:595-601 (and :900-905), result flattening
+ * :604-609.  Exact batched inner-product k-NN (rows are unit-norm => cosine), fused
+ * Q x corpus^T MFMA GEMM + per-query top-k selection; the [B, n] score matrix never
+ * reaches HBM.
+ *
+ *   q          dev [B, ld]      queries, dtype `dtype`, pad columns zero
+ *   corpus     dev [n, ld]      this shard's rows, same dtype / ld, pad columns zero
+ *   ld         = mmrag_padded_dim(d, dtype) or any larger multiple of it
+ *   k          1..MMRAG_MAX_K
+ *   row_offset added to local row numbers => global row ids (shard base)
+ *   alive_bits dev, optional (NULL = all alive): bit r%32 of word r/32 set <=> row r may be
+ *              returned (delete_document tombstones embedder.py:619-656, `where` filters :599)
+ *   out_scores dev [B, k] float32, descending; ties -> lower row first
+ *   out_rows   dev [B, k] int64 global rows; (-inf, -1) padding when fewer than k live rows
+ *   workspace  dev, >= mmrag_cosine_topk_workspace_bytes(B, n, k) bytes, 16-byte aligned
+ * ------------------------------------------------------------------------------------- */
+size_t mmrag_cosine_topk_workspace_bytes(int B, int64_t n, int k);
+
+int mmrag_cosine_topk(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld,
+                      int dtype, int k, int64_t row_offset, const uint32_t *alive_bits,
+                      float *out_scores, int64_t *out_rows, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* Merge G shards' local top-k (layout [G, B, k_in], as produced by an all-gather of
+ * mmrag_cosine_topk outputs) into the global top-k [B, k].  Device version (one tiny
+ * kernel) and host version (north star: "final host merge"); identical ordering rule.
+ * Replaces nothing in the reference (it is single-process); it is the exchange step of the
+ * row-sharded index. */
+int mmrag_merge_topk(const float *scores, const int64_t *rows, int G, int B, int k_in, int k,
+                     float *out_scores, int64_t *out_rows, void *stream);
+int mmrag_merge_topk_host(const float *scores, const int64_t *rows, int G, int B, int k_in,
+                          int k, float *out_scores, int64_t *out_rows);
+
+/* ---------------------------------------------------------------------------------------
+ * Store.  Replaces chromadb's  collection.add(embeddings=..., ...)  vector half
+ * (app/utils/embedder.py:514-523): cast + copy `m` new float32 rows into the shard matrix
+ * at row n_used (the id/metadata/document table stays on the host).
+ *   corpus  dev [capacity, ld] dtype   new_rows dev [m, d] float32 (tightly packed)
+ * ------------------------------------------------------------------------------------- */
+int mmrag_append_rows(void *corpus, int64_t capacity, int64_t ld, int dtype, int64_t n_used,
+                      const float *new_rows, int64_t m, int d, void *stream);
+
+/* Stable compaction after deletes (collection.delete, embedder.py:639-642):
+ * dst[i, :] = src[keep_rows[i], :] for i < m.  dst and src must not overlap. */
+int mmrag_gather_rows(void *dst, const void *src, int64_t ld, int dtype,
+                      const int64_t *keep_rows, int64_t m, void *stream);
+
+/* Fetch stored vectors as float32 (collection.get(ids, include=['embeddings']),
+ * embedder.py:887-897): out[i, :d] = float(corpus[rows[i], :d]). */
+int mmrag_fetch_rows_f32(const void *corpus, int64_t ld, int dtype, const int64_t *rows,
+                         int64_t m, int d, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMRAG_H */

@@ -1,0 +1,193 @@
+"""ctypes binding of libmmrag.so (include/mmrag.h) -- the only way the package computes.
+
+There is no CPU / PyTorch-eager fallback: if the shared library is missing or a call
+returns a non-zero status this module raises.  torch is used for device memory and the
+current HIP stream only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmmrag.so")
+
+F32, F16, BF16 = 0, 1, 2
+MAX_K = 20
+_TORCH2DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+_DT2TORCH = {v: k for k, v in _TORCH2DT.items()}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class MMRagNativeError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    lib.mmrag_abi_version.restype = c_int
+    lib.mmrag_last_error.restype = c_char_p
+    lib.mmrag_padded_dim.restype = c_int64
+    lib.mmrag_padded_dim.argtypes = [c_int, c_int]
+    lib.mmrag_cosine_topk_workspace_bytes.restype = c_size_t
+    lib.mmrag_cosine_topk_workspace_bytes.argtypes = [c_int, c_int64, c_int]
+    lib.mmrag_cosine_topk.restype = c_int
+    lib.mmrag_cosine_topk.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_int,
+                                      c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_merge_topk.restype = c_int
+    lib.mmrag_merge_topk.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.mmrag_merge_topk_host.restype = c_int
+    lib.mmrag_merge_topk_host.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.mmrag_append_rows.restype = c_int
+    lib.mmrag_append_rows.argtypes = [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_int64, c_int, c_void_p]
+    lib.mmrag_gather_rows.restype = c_int
+    lib.mmrag_gather_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
+    lib.mmrag_fetch_rows_f32.restype = c_int
+    lib.mmrag_fetch_rows_f32.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]
+    if hasattr(lib, "mmrag_encoder_workspace_bytes"):
+        lib.mmrag_encoder_workspace_bytes.restype = c_size_t
+        lib.mmrag_encoder_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+        lib.mmrag_encoder_forward.restype = c_int
+        lib.mmrag_encoder_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                              c_void_p, c_void_p, c_size_t, c_void_p]
+
+
+def lib():
+    """Load libmmrag.so once (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise MMRagNativeError(
+                        f"{LIB_PATH} is missing: build it with `python -m multimodal_rag_amd.build` "
+                        "(hipcc, gfx950).  There is no CPU fallback.")
+                handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+                _declare(handle)
+                _lib = handle
+    return _lib
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        msg = lib().mmrag_last_error().decode("utf-8", "replace")
+        raise MMRagNativeError(f"{what} failed (status {status}): {msg}")
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MMRagNativeError("libmmrag entry points take device (HIP) tensors only; got a CPU tensor")
+
+
+def padded_dim(d: int, dtype: torch.dtype) -> int:
+    v = lib().mmrag_padded_dim(int(d), _TORCH2DT[dtype])
+    if v < 0:
+        raise MMRagNativeError(f"padded_dim: bad arguments d={d} dtype={dtype}")
+    return int(v)
+
+
+def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, row_offset: int = 0,
+                alive_bits: Optional[torch.Tensor] = None,
+                workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact cosine top-k of q [B, ld] against the first n rows of corpus [cap, ld].
+
+    Returns (scores [B, k] float32 descending, rows [B, k] int64 global).  Both inputs must be
+    contiguous, same dtype, same padded leading dimension (pad columns zero).
+    """
+    _dev_check(q, corpus, alive_bits)
+    if q.dim() != 2 or corpus.dim() != 2 or not q.is_contiguous() or not corpus.is_contiguous():
+        raise MMRagNativeError("cosine_topk: q and corpus must be contiguous 2-D tensors")
+    if q.dtype != corpus.dtype or q.shape[1] != corpus.shape[1]:
+        raise MMRagNativeError("cosine_topk: q and corpus must share dtype and padded width")
+    if n > corpus.shape[0]:
+        raise MMRagNativeError(f"cosine_topk: n={n} exceeds corpus capacity {corpus.shape[0]}")
+    B, ld = q.shape
+    L = lib()
+    need = L.mmrag_cosine_topk_workspace_bytes(B, n, k)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    out_s = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    out_r = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    with torch.cuda.device(q.device):
+        st = L.mmrag_cosine_topk(q.data_ptr(), corpus.data_ptr(), B, n, d, ld, _TORCH2DT[q.dtype], k, row_offset,
+                                 alive_bits.data_ptr() if alive_bits is not None else None,
+                                 out_s.data_ptr(), out_r.data_ptr(), workspace.data_ptr(),
+                                 workspace.numel() * workspace.element_size(), _stream_ptr(q.device))
+    _check(st, "mmrag_cosine_topk")
+    return out_s, out_r
+
+
+def cosine_topk_workspace_bytes(B: int, n: int, k: int) -> int:
+    return int(lib().mmrag_cosine_topk_workspace_bytes(B, n, k))
+
+
+def merge_topk(scores: torch.Tensor, rows: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Device merge of [G, B, k_in] shard results into [B, k]."""
+    _dev_check(scores, rows)
+    G, B, k_in = scores.shape
+    scores = scores.contiguous()
+    rows = rows.contiguous()
+    out_s = torch.empty((B, k), dtype=torch.float32, device=scores.device)
+    out_r = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        st = lib().mmrag_merge_topk(scores.data_ptr(), rows.data_ptr(), G, B, k_in, k, out_s.data_ptr(),
+                                    out_r.data_ptr(), _stream_ptr(scores.device))
+    _check(st, "mmrag_merge_topk")
+    return out_s, out_r
+
+
+def merge_topk_host(scores: torch.Tensor, rows: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host (C++) merge of [G, B, k_in] shard results held in CPU tensors into [B, k]."""
+    if scores.is_cuda or rows.is_cuda:
+        raise MMRagNativeError("merge_topk_host takes CPU tensors")
+    G, B, k_in = scores.shape
+    scores = scores.contiguous().to(torch.float32)
+    rows = rows.contiguous().to(torch.int64)
+    out_s = torch.empty((B, k), dtype=torch.float32)
+    out_r = torch.empty((B, k), dtype=torch.int64)
+    st = lib().mmrag_merge_topk_host(scores.data_ptr(), rows.data_ptr(), G, B, k_in, k, out_s.data_ptr(),
+                                     out_r.data_ptr())
+    _check(st, "mmrag_merge_topk_host")
+    return out_s, out_r
+
+
+def append_rows(corpus: torch.Tensor, n_used: int, new_rows: torch.Tensor, d: int) -> None:
+    """corpus[n_used : n_used+m, :d] = cast(new_rows) with zero pad columns."""
+    _dev_check(corpus, new_rows)
+    new_rows = new_rows.to(torch.float32).contiguous()
+    m = new_rows.shape[0]
+    with torch.cuda.device(corpus.device):
+        st = lib().mmrag_append_rows(corpus.data_ptr(), corpus.shape[0], corpus.shape[1], _TORCH2DT[corpus.dtype],
+                                     n_used, new_rows.data_ptr(), m, d, _stream_ptr(corpus.device))
+    _check(st, "mmrag_append_rows")
+
+
+def gather_rows(dst: torch.Tensor, src: torch.Tensor, keep_rows: torch.Tensor) -> None:
+    _dev_check(dst, src, keep_rows)
+    keep_rows = keep_rows.to(torch.int64).contiguous()
+    with torch.cuda.device(src.device):
+        st = lib().mmrag_gather_rows(dst.data_ptr(), src.data_ptr(), src.shape[1], _TORCH2DT[src.dtype],
+                                     keep_rows.data_ptr(), keep_rows.numel(), _stream_ptr(src.device))
+    _check(st, "mmrag_gather_rows")
+
+
+def fetch_rows_f32(corpus: torch.Tensor, rows: torch.Tensor, d: int) -> torch.Tensor:
+    _dev_check(corpus, rows)
+    rows = rows.to(torch.int64).contiguous()
+    out = torch.empty((rows.numel(), d), dtype=torch.float32, device=corpus.device)
+    with torch.cuda.device(corpus.device):
+        st = lib().mmrag_fetch_rows_f32(corpus.data_ptr(), corpus.shape[1], _TORCH2DT[corpus.dtype], rows.data_ptr(),
+                                        rows.numel(), d, out.data_ptr(), _stream_ptr(corpus.device))
+    _check(st, "mmrag_fetch_rows_f32")
+    return out

@@ -1,0 +1,36 @@
+// Internal helpers shared by the libmmrag.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mmrag.h"
+
+namespace mmrag {
+
+void set_error(const char *fmt, ...);
+
+inline int esize(int dtype) { return dtype == MMRAG_F32 ? 4 : 2; }
+
+#define MMRAG_CHECK_ARG(cond, ...)            \
+    do {                                      \
+        if (!(cond)) {                        \
+            mmrag::set_error(__VA_ARGS__);    \
+            return MMRAG_EINVAL;              \
+        }                                     \
+    } while (0)
+
+#define MMRAG_CHECK_HIP(expr)                                                     \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            mmrag::set_error("%s failed: %s", #expr, hipGetErrorString(e_));      \
+            return MMRAG_EHIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+// number of CUs of the current device (cached per device id)
+int num_cus();
+
+}  // namespace mmrag

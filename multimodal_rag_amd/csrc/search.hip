@@ -1,0 +1,589 @@
+// Fused cosine GEMM + top-k for gfx950 (MI355X): the retrieve half of the hot path.
+//
+// Replaces chromadb's collection.query (reference call site app/utils/embedder.py:595-601)
+// with an exact search:  S = corpus . Q^T  on the matrix cores, top-k selected in the GEMM
+// epilogue, so the [B, n] score matrix never exists in HBM.
+//
+// Shape of the computation (DESIGN.md "search kernel"):
+//   * persistent grid: one 512-thread workgroup per CU walks corpus tiles of 256 rows
+//     (tile = blockIdx.x + i * gridDim.x); HBM traffic = the corpus, read exactly once;
+//   * K is streamed in 128-byte slabs (64 fp16 / 32 fp32 per row) through an NSTAGE-deep
+//     LDS ring filled by LDS-DMA (`buffer_load_dwordx4 ... lds`, bounds-checked by the
+//     buffer descriptor so ragged tiles read zeros); the query slab rides along (L2-resident);
+//   * LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the
+//     DMA *source* address and on the ds_read_b128 address (conflict-free fragment reads);
+//   * MFMA orientation D[corpus row][query] = A(corpus) x B(Q^T): the query sits on the
+//     lane (col = lane & 31), corpus rows sit in the 16 accumulator registers, so top-k
+//     selection per query is lane-local register work with no cross-lane traffic;
+//   * 8 waves = WM x WN; each wave owns 32 queries x (256/WM) corpus rows;
+//   * selection: each lane keeps a sorted K-list (score desc) for its query over the rows it
+//     sees; an element enters only if it beats a running threshold (k-th best of the union
+//     of the two half-wave lists of that query) -- after the first tiles almost nothing does;
+//   * masked / out-of-range rows start their accumulator at -inf, so they cost nothing in
+//     the epilogue;
+//   * every lane list is written once at kernel end; a second tiny kernel merges the
+//     gridDim.x * WM * 2 lists per query into the final [B, k] (ties -> lower row).
+#include "mmrag_internal.h"
+
+#include <limits.h>
+
+using namespace mmrag;
+
+namespace mmrag_impl {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+constexpr int TM = 256;            // corpus rows per tile
+constexpr int SLAB = 128;          // bytes of K per row per stage
+constexpr int NTHREADS = 512;
+constexpr int CORPUS_STAGE = TM * SLAB;  // 32 KiB
+constexpr float NEG_INF = -__builtin_inff();
+
+template <int K>
+struct TopList {
+    float v[K];
+    int r[K];
+    __device__ inline void init() {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            v[i] = NEG_INF;
+            r[i] = INT_MAX;
+        }
+    }
+    // insertion order == row order inside a lane, so "strictly greater" keeps the lower row on ties
+    __device__ inline void insert_strict(float x, int xr) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool b = x > v[j];
+            const float nv = b ? x : v[j];
+            const float nx = b ? v[j] : x;
+            const int nr = b ? xr : r[j];
+            const int nxr = b ? r[j] : xr;
+            v[j] = nv;
+            x = nx;
+            r[j] = nr;
+            xr = nxr;
+        }
+    }
+};
+
+__device__ inline bool better(float s, long long r, float s2, long long r2) {
+    return s > s2 || (s == s2 && r < r2);
+}
+
+template <int N>
+__device__ inline void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `items` later ring items (LOADS wave-instructions each) are outstanding
+template <int LOADS, int MAXITEMS>
+__device__ inline void wait_items(int items) {
+    if constexpr (MAXITEMS >= 2) {
+        if (items >= 2) {
+            wait_vmcnt<2 * LOADS>();
+            return;
+        }
+    }
+    if constexpr (MAXITEMS >= 1) {
+        if (items >= 1) {
+            wait_vmcnt<LOADS>();
+            return;
+        }
+    }
+    wait_vmcnt<0>();
+}
+
+struct KParams {
+    const char *q;        // [B, ld]
+    const char *corpus;   // [n, ld]
+    const uint32_t *alive_bits;
+    float *cand_s;        // [Bpad, n_lists, K]
+    int *cand_r;
+    long long n;
+    int B;
+    unsigned row_bytes;   // ld * esize, multiple of 128
+    int n_tiles;
+    int n_lists;          // gridDim.x * WM * 2
+};
+
+template <int DT, int WN, int K, int NSTAGE>
+__global__ __launch_bounds__(NTHREADS, 2) void cosine_topk_kernel(const KParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // amdgcn builtins below: the host pass only needs the launch stub
+    constexpr int WM = 8 / WN;           // waves along corpus rows
+    constexpr int RM = 8 / WM;           // 32-row blocks per wave  (== WN)
+    constexpr int QROWS = 32 * WN;
+    constexpr int STAGE = CORPUS_STAGE + QROWS * SLAB;
+    constexpr int QLOADS = WN / 2;       // 1 KiB DMA instructions per wave for the Q slab
+    constexpr int LOADS = 4 + QLOADS;    // per wave per ring item
+    static_assert(WN == 2 || WN == 4 || WN == 8, "WN");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "NSTAGE");
+    static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
+
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+
+    const unsigned RB = p.row_bytes;
+    const int nk = (int)(RB / SLAB);
+    const int q0 = blockIdx.y * QROWS;
+    const int my_tiles = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_items = my_tiles * nk;
+
+    // ---- DMA descriptors ------------------------------------------------------------------
+    const long long q_rows_left = (long long)p.B - q0;
+    const unsigned q_bytes = (unsigned)((q_rows_left < QROWS ? q_rows_left : QROWS) * (long long)RB);
+    const __amdgpu_buffer_rsrc_t rsrc_q =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.q + (size_t)q0 * RB), 0, q_bytes, 0x00020000);
+
+    // per-lane source offsets (row * RB + swizzled chunk * 16) for this wave's DMA instructions
+    const int dma_row = lane >> 3;        // row inside an 8-row (1 KiB) LDS piece
+    const int dma_slot = lane & 7;        // 16-byte slot inside the 128-byte LDS row
+    unsigned c_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + dma_row;
+        c_off[i] = (unsigned)row * RB + (unsigned)((dma_slot ^ ((row >> 1) & 7)) * 16);
+    }
+    unsigned q_off[QLOADS];
+#pragma unroll
+    for (int i = 0; i < QLOADS; ++i) {
+        const int row = (wave * QLOADS + i) * 8 + dma_row;
+        q_off[i] = (unsigned)row * RB + (unsigned)((dma_slot ^ ((row >> 1) & 7)) * 16);
+    }
+
+    int is_tile = 0, is_k = 0;  // issue cursor: (index among my tiles, k slab)
+    auto issue = [&](int stage_idx) {
+        const long long tile = (long long)blockIdx.x + (long long)is_tile * gridDim.x;
+        const long long row0 = tile * TM;
+        const long long rows_left = p.n - row0;
+        const unsigned c_bytes = (unsigned)((rows_left < TM ? rows_left : (long long)TM) * (long long)RB);
+        const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(p.corpus + (size_t)row0 * RB), 0, c_bytes, 0x00020000);
+        char *st = smem + stage_idx * STAGE;
+        const unsigned koff = (unsigned)is_k * SLAB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + (wave * 4 + i) * 1024), 16,
+                                                     c_off[i] + koff, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < QLOADS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc_q, (lds_ptr_t)(st + CORPUS_STAGE + (wave * QLOADS + i) * 1024), 16, q_off[i] + koff, 0,
+                0, 0);
+        if (++is_k == nk) {
+            is_k = 0;
+            ++is_tile;
+        }
+    };
+
+    // ---- accumulators, lists ---------------------------------------------------------------
+    f32x16_t acc[RM];
+    auto init_acc = [&](int tile_idx) {
+        const long long tile = (long long)blockIdx.x + (long long)tile_idx * gridDim.x;
+        const long long row0 = tile * TM + (long long)wm * (RM * 32);
+        const bool ragged = row0 + RM * 32 > p.n;
+        if (!ragged && p.alive_bits == nullptr) {
+#pragma unroll
+            for (int b = 0; b < RM; ++b)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[b][j] = 0.0f;
+            return;
+        }
+#pragma unroll
+        for (int b = 0; b < RM; ++b) {
+            const long long brow = row0 + b * 32;
+            unsigned bits = 0xffffffffu;
+            if (p.alive_bits != nullptr && brow < p.n) bits = p.alive_bits[brow >> 5];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rr = (j & 3) + 8 * (j >> 2) + 4 * h;
+                const bool ok = (brow + rr < p.n) && ((bits >> rr) & 1u);
+                acc[b][j] = ok ? 0.0f : NEG_INF;
+            }
+        }
+    };
+
+    TopList<K> best;
+    best.init();
+    float thr = NEG_INF;
+
+    // ---- fragment addresses (bytes inside a stage) ------------------------------------------
+    const int sw = (r32 >> 1) & 7;
+    const int a_base = (wm * RM * 32 + r32) * SLAB;
+    const int b_base = CORPUS_STAGE + (wn * 32 + r32) * SLAB;
+
+    // ---- prologue ---------------------------------------------------------------------------
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < n_items; ++issued) issue(issued);
+    init_acc(0);
+
+    int tile_idx = 0, ks = 0;
+    for (int it = 0; it < n_items; ++it) {
+        wait_items<LOADS, NSTAGE - 2>(issued - it - 1);
+        __builtin_amdgcn_s_barrier();
+        if (issued < n_items) {
+            issue(issued % NSTAGE);
+            ++issued;
+        }
+        const char *st = smem + (it % NSTAGE) * STAGE;
+
+        if constexpr (DT == MMRAG_F32) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int off = ((2 * m + h) ^ sw) * 16;
+                const f32x4_t bq = *(const f32x4_t *)(st + b_base + off);
+#pragma unroll
+                for (int b = 0; b < RM; ++b) {
+                    const f32x4_t ac = *(const f32x4_t *)(st + a_base + b * (32 * SLAB) + off);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i], bq[i], acc[b], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int off = ((2 * m + h) ^ sw) * 16;
+                if constexpr (DT == MMRAG_F16) {
+                    const half8_t bq = *(const half8_t *)(st + b_base + off);
+#pragma unroll
+                    for (int b = 0; b < RM; ++b) {
+                        const half8_t ac = *(const half8_t *)(st + a_base + b * (32 * SLAB) + off);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac, bq, acc[b], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8_t bq = *(const bf16x8_t *)(st + b_base + off);
+#pragma unroll
+                    for (int b = 0; b < RM; ++b) {
+                        const bf16x8_t ac = *(const bf16x8_t *)(st + a_base + b * (32 * SLAB) + off);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac, bq, acc[b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        if (++ks == nk) {
+            // ---- epilogue: lane-local top-K over this wave's 32*RM rows of the tile ----------
+            ks = 0;
+            const long long tile = (long long)blockIdx.x + (long long)tile_idx * gridDim.x;
+            const int row_base = (int)(tile * TM) + wm * (RM * 32) + 4 * h;
+#pragma unroll
+            for (int b = 0; b < RM; ++b) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float s = acc[b][j];
+                    const bool pass = s >= thr;
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                        best.insert_strict(pass ? s : NEG_INF, row_base + b * 32 + (j & 3) + 8 * (j >> 2));
+                        thr = fmaxf(thr, best.v[K - 1]);
+                    }
+                }
+            }
+            // k-th best of the union of the two half-wave lists of this query: a lower bound
+            // on the final k-th score, shared by both lanes
+            float u = fmaxf(best.v[K - 1], __shfl_xor(best.v[K - 1], 32));
+#pragma unroll
+            for (int i = 0; i + 1 < K; ++i) u = fmaxf(u, fminf(best.v[i], __shfl_xor(best.v[K - 2 - i], 32)));
+            thr = fmaxf(thr, u);
+            ++tile_idx;
+            if (tile_idx < my_tiles) init_acc(tile_idx);
+        }
+    }
+
+    // ---- write this lane's list ---------------------------------------------------------------
+    const int q = q0 + wn * 32 + r32;
+    if (q < p.B) {
+        const int list = ((int)blockIdx.x * WM + wm) * 2 + h;
+        const size_t base = ((size_t)q * p.n_lists + list) * K;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            p.cand_s[base + i] = best.v[i];
+            p.cand_r[base + i] = best.r[i];
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge: per query, reduce `n_cand` (score, row) candidates to the top-k under (score desc,
+// row asc).  One 256-thread workgroup per query.  Candidate c of query q lives at
+//   (c / inner) * outer_stride + q * q_stride + (c % inner)
+// which covers both the kernel's [B, n_lists*K] lists (inner = n_cand) and an all-gathered
+// [G, B, k] block (inner = k, outer_stride = B*k, q_stride = k).
+// ---------------------------------------------------------------------------------------------
+template <int K>
+struct FullList {
+    float v[K];
+    long long r[K];
+    __device__ inline void init() {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            v[i] = NEG_INF;
+            r[i] = LLONG_MAX;
+        }
+    }
+    __device__ inline void insert(float x, long long xr) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool b = better(x, xr, v[j], r[j]);
+            const float nv = b ? x : v[j];
+            const float nx = b ? v[j] : x;
+            const long long nr = b ? xr : r[j];
+            const long long nxr = b ? r[j] : xr;
+            v[j] = nv;
+            x = nx;
+            r[j] = nr;
+            xr = nxr;
+        }
+    }
+    __device__ inline void pop() {
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) {
+            v[j] = v[j + 1];
+            r[j] = r[j + 1];
+        }
+        v[K - 1] = NEG_INF;
+        r[K - 1] = LLONG_MAX;
+    }
+};
+
+// K rounds of wave-wide arg-best over the lanes' list heads; lane 0 receives the results
+template <int K>
+__device__ inline void wave_extract(FullList<K> &l, float *out_v, long long *out_r) {
+#pragma unroll
+    for (int round = 0; round < K; ++round) {
+        float s = l.v[0];
+        long long r = l.r[0];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float os = __shfl_xor(s, off);
+            const long long orr = __shfl_xor(r, off);
+            if (better(os, orr, s, r)) {
+                s = os;
+                r = orr;
+            }
+        }
+        out_v[round] = s;
+        out_r[round] = r;
+        if (l.v[0] == s && l.r[0] == r) l.pop();
+    }
+}
+
+template <int K, typename RowT>
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ cs,
+                                                          const RowT *__restrict__ cr, long long n_cand,
+                                                          long long inner, long long outer_stride,
+                                                          long long q_stride, int k_out,
+                                                          long long row_offset, float *__restrict__ out_s,
+                                                          long long *__restrict__ out_r) {
+    __shared__ float sh_v[4 * K];
+    __shared__ long long sh_r[4 * K];
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr long long PAD = sizeof(RowT) == 4 ? (long long)INT_MAX : LLONG_MAX;
+
+    FullList<K> l;
+    l.init();
+    for (long long c = threadIdx.x; c < n_cand; c += 256) {
+        const long long a = (c / inner) * outer_stride + (long long)q * q_stride + (c % inner);
+        const float s = cs[a];
+        long long r = (long long)cr[a];
+        if (r == PAD || r < 0) continue;  // padding entry
+        if (better(s, r, l.v[K - 1], l.r[K - 1])) l.insert(s, r);
+    }
+    float ov[K];
+    long long orr[K];
+    wave_extract<K>(l, ov, orr);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            sh_v[wave * K + i] = ov[i];
+            sh_r[wave * K + i] = orr[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        l.init();
+        for (int i = lane; i < 4 * K; i += 64)
+            if (sh_r[i] != LLONG_MAX) l.insert(sh_v[i], sh_r[i]);
+        wave_extract<K>(l, ov, orr);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (i < k_out) {
+                    const bool valid = orr[i] != LLONG_MAX && ov[i] > NEG_INF;
+                    out_s[(size_t)q * k_out + i] = valid ? ov[i] : NEG_INF;
+                    out_r[(size_t)q * k_out + i] = valid ? orr[i] + row_offset : -1;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------
+struct Plan {
+    int K;        // list depth: 5, 10 or 20
+    int WN;       // waves along queries
+    int grid_x, grid_y;
+    int n_tiles;
+    int n_lists;
+    int b_pad;
+};
+
+Plan make_plan(int B, long long n, int k) {
+    Plan pl;
+    pl.K = k <= 5 ? 5 : (k <= 10 ? 10 : 20);
+    if (pl.K == 5)
+        pl.WN = B <= 64 ? 2 : (B <= 128 ? 4 : 8);
+    else
+        pl.WN = 2;  // deep lists: keep the unrolled epilogue small (32 accumulators per lane)
+    const int qrows = 32 * pl.WN;
+    pl.grid_y = (B + qrows - 1) / qrows;
+    pl.n_tiles = (int)((n + TM - 1) / TM);
+    const int cus = num_cus();
+    pl.grid_x = pl.n_tiles < cus ? pl.n_tiles : cus;
+    if (pl.grid_x < 1) pl.grid_x = 1;
+    pl.n_lists = pl.grid_x * (8 / pl.WN) * 2;
+    pl.b_pad = pl.grid_y * qrows;
+    return pl;
+}
+
+template <int DT, int WN, int K, int NSTAGE>
+void launch_main(const KParams &p, dim3 grid, hipStream_t s) {
+    cosine_topk_kernel<DT, WN, K, NSTAGE><<<grid, NTHREADS, 0, s>>>(p);
+}
+
+template <int DT>
+int dispatch_main(const Plan &pl, const KParams &p, hipStream_t s) {
+    dim3 grid(pl.grid_x, pl.grid_y);
+    if (pl.K == 5) {
+        if (pl.WN == 2) launch_main<DT, 2, 5, 3>(p, grid, s);
+        else if (pl.WN == 4) launch_main<DT, 4, 5, 3>(p, grid, s);
+        else launch_main<DT, 8, 5, 2>(p, grid, s);
+    } else if (pl.K == 10) {
+        launch_main<DT, 2, 10, 3>(p, grid, s);
+    } else {
+        launch_main<DT, 2, 20, 3>(p, grid, s);
+    }
+    return MMRAG_OK;
+}
+
+template <typename RowT>
+int launch_merge(int K, const float *cs, const RowT *cr, long long n_cand, long long inner,
+                 long long outer_stride, long long q_stride, int B, int k_out, long long row_offset,
+                 float *out_s, long long *out_r, hipStream_t s) {
+    if (K == 5)
+        merge_topk_kernel<5, RowT><<<B, 256, 0, s>>>(cs, cr, n_cand, inner, outer_stride, q_stride, k_out,
+                                                     row_offset, out_s, out_r);
+    else if (K == 10)
+        merge_topk_kernel<10, RowT><<<B, 256, 0, s>>>(cs, cr, n_cand, inner, outer_stride, q_stride, k_out,
+                                                      row_offset, out_s, out_r);
+    else
+        merge_topk_kernel<20, RowT><<<B, 256, 0, s>>>(cs, cr, n_cand, inner, outer_stride, q_stride, k_out,
+                                                      row_offset, out_s, out_r);
+    return MMRAG_OK;
+}
+
+__global__ void fill_empty_kernel(float *s, long long *r, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        s[i] = NEG_INF;
+        r[i] = -1;
+    }
+}
+
+}  // namespace mmrag_impl
+using namespace mmrag_impl;
+
+extern "C" {
+
+size_t mmrag_cosine_topk_workspace_bytes(int B, int64_t n, int k) {
+    if (B <= 0 || n < 0 || k < 1 || k > MMRAG_MAX_K) return 0;
+    const Plan pl = make_plan(B, n, k);
+    const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
+    return entries * (sizeof(float) + sizeof(int)) + 256;
+}
+
+int mmrag_cosine_topk(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
+                      int k, int64_t row_offset, const uint32_t *alive_bits, float *out_scores,
+                      int64_t *out_rows, void *workspace, size_t workspace_bytes, void *stream) {
+    MMRAG_CHECK_ARG(dtype >= 0 && dtype <= 2, "cosine_topk: bad dtype %d", dtype);
+    MMRAG_CHECK_ARG(B > 0, "cosine_topk: B must be positive (got %d)", B);
+    MMRAG_CHECK_ARG(k >= 1 && k <= MMRAG_MAX_K, "cosine_topk: k=%d outside 1..%d", k, MMRAG_MAX_K);
+    MMRAG_CHECK_ARG(n >= 0 && n < (int64_t)INT_MAX - TM, "cosine_topk: n=%lld out of range", (long long)n);
+    MMRAG_CHECK_ARG(d > 0 && ld >= d, "cosine_topk: need 0 < d <= ld (d=%d ld=%lld)", d, (long long)ld);
+    const int64_t row_bytes = ld * esize(dtype);
+    MMRAG_CHECK_ARG(row_bytes % SLAB == 0, "cosine_topk: row bytes %lld not a multiple of %d (use mmrag_padded_dim)",
+                    (long long)row_bytes, SLAB);
+    MMRAG_CHECK_ARG(row_bytes * TM < (int64_t)UINT_MAX, "cosine_topk: rows too long");
+    MMRAG_CHECK_ARG(q && out_scores && out_rows, "cosine_topk: null pointer");
+    MMRAG_CHECK_ARG(n == 0 || corpus, "cosine_topk: null corpus");
+    MMRAG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)corpus % 16) == 0, "cosine_topk: q/corpus must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+
+    if (n == 0) {
+        const long long total = (long long)B * k;
+        fill_empty_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(out_scores, (long long *)out_rows, total);
+        MMRAG_CHECK_HIP(hipGetLastError());
+        return MMRAG_OK;
+    }
+
+    const Plan pl = make_plan(B, n, k);
+    const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
+    const size_t need = entries * (sizeof(float) + sizeof(int));
+    if (!workspace || workspace_bytes < need) {
+        set_error("cosine_topk: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MMRAG_EWORKSPACE;
+    }
+    MMRAG_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "cosine_topk: workspace must be 16-byte aligned");
+
+    KParams p;
+    p.q = (const char *)q;
+    p.corpus = (const char *)corpus;
+    p.alive_bits = alive_bits;
+    p.cand_s = (float *)workspace;
+    p.cand_r = (int *)((char *)workspace + entries * sizeof(float));
+    p.n = n;
+    p.B = B;
+    p.row_bytes = (unsigned)row_bytes;
+    p.n_tiles = pl.n_tiles;
+    p.n_lists = pl.n_lists;
+
+    if (dtype == MMRAG_F32) dispatch_main<MMRAG_F32>(pl, p, s);
+    else if (dtype == MMRAG_F16) dispatch_main<MMRAG_F16>(pl, p, s);
+    else dispatch_main<MMRAG_BF16>(pl, p, s);
+    MMRAG_CHECK_HIP(hipGetLastError());
+
+    const long long n_cand = (long long)pl.n_lists * pl.K;
+    launch_merge<int>(pl.K, p.cand_s, p.cand_r, n_cand, n_cand, 0, n_cand, B, k, row_offset, out_scores,
+                      (long long *)out_rows, s);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_merge_topk(const float *scores, const int64_t *rows, int G, int B, int k_in, int k,
+                     float *out_scores, int64_t *out_rows, void *stream) {
+    MMRAG_CHECK_ARG(scores && rows && out_scores && out_rows, "merge_topk: null pointer");
+    MMRAG_CHECK_ARG(G > 0 && B > 0 && k_in > 0, "merge_topk: bad shape G=%d B=%d k_in=%d", G, B, k_in);
+    MMRAG_CHECK_ARG(k >= 1 && k <= MMRAG_MAX_K, "merge_topk: k=%d outside 1..%d", k, MMRAG_MAX_K);
+    const int K = k <= 5 ? 5 : (k <= 10 ? 10 : 20);
+    launch_merge<long long>(K, scores, (const long long *)rows, (long long)G * k_in, k_in, (long long)B * k_in,
+                            k_in, B, k, 0, out_scores, (long long *)out_rows, (hipStream_t)stream);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+}  // extern "C"

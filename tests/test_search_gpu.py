@@ -1,0 +1,167 @@
+"""GPU parity: libmmrag's fused cosine GEMM + top-k (through the C-ABI) vs the CPU oracle.
+
+Bar: identical top-k id sets (candidates within 2e-4 of the k-th score
+interchangeable), cosine within 1e-4; on exactly representable integer data: bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import search_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north star: "cosine scores within 1e-4 fp32"
+
+
+@pytest.fixture(scope="module")
+def N():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodal_rag_amd import _native
+
+    _native.lib()
+    return _native
+
+
+def unit_rows(n, d, seed):
+    g = np.random.default_rng(seed)
+    x = g.standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def to_dev(N, x, dtype):
+    """pad to the kernel's leading dimension, cast to storage dtype; also return the exact
+    float32 view of the stored values for the oracle"""
+    n, d = x.shape
+    ld = N.padded_dim(d, dtype)
+    t = torch.zeros((max(n, 1), ld), dtype=dtype, device="cuda")
+    if n:
+        t[:n, :d] = torch.from_numpy(x).to("cuda").to(dtype)
+    stored = t[:n, :d].to(torch.float32).cpu().numpy()
+    return t, stored
+
+
+def run(N, q, c, k, dtype, row_offset=0, alive=None):
+    qd, qs = to_dev(N, q, dtype)
+    cd, cs = to_dev(N, c, dtype)
+    bits = None
+    if alive is not None:
+        words = np.zeros((c.shape[0] + 31) // 32 + 8, dtype=np.uint32)
+        idx = np.nonzero(alive)[0]
+        np.bitwise_or.at(words, idx // 32, (np.uint32(1) << (idx % 32).astype(np.uint32)))
+        bits = torch.from_numpy(words.view(np.int32)).to("cuda")
+    s, r = N.cosine_topk(qd, cd, c.shape[0], c.shape[1], k, row_offset=row_offset, alive_bits=bits)
+    torch.cuda.synchronize()
+    es, er = O.cosine_topk(qs, cs, k, row_offset=row_offset, alive=alive)
+    return s.cpu().numpy(), r.cpu().numpy(), es, er
+
+
+def check(s, r, es, er):
+    assert r.shape == er.shape and s.shape == es.shape
+    fin = np.isfinite(es)
+    assert np.array_equal(np.isfinite(s), fin)
+    assert np.array_equal(r[~fin], er[~fin])  # -1 padding
+    assert np.all(np.abs(s[fin] - es[fin]) <= TOL)
+    assert np.all(np.diff(s, axis=1)[fin[:, 1:]] <= 0)  # descending
+    assert O.same_topk_sets(r, s, er, es)
+
+
+def test_wal70_golden(N, wal70):
+    """real all-MiniLM-L6-v2 vectors from the reference's Chroma WAL: all-pairs top-5"""
+    V = wal70["vectors"]
+    s, r, es, er = run(N, V, V, 5, torch.float32)
+    assert np.array_equal(r, wal70["top_rows"])
+    assert np.all(np.abs(s - wal70["top_cos"]) <= 1e-5)
+    assert np.array_equal(r, er)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n,d,k", [
+    (1, 1000, 384, 5), (33, 5003, 384, 5), (64, 777, 768, 3), (100, 9000, 768, 5),
+    (256, 20000, 768, 5), (300, 4097, 512, 5), (7, 2500, 100, 10), (70, 3000, 384, 20), (5, 300, 64, 1),
+])
+def test_random_parity(N, dtype, B, n, d, k):
+    q = unit_rows(B, d, 1)
+    c = unit_rows(n, d, 2)
+    check(*run(N, q, c, k, dtype))
+
+
+def test_exact_integers_catch_layout_swaps(N):
+    """small-integer data is exact in fp16/fp32: any fragment/row-map mistake changes ids"""
+    g = np.random.default_rng(5)
+    n, d, B = 1500, 128, 96
+    c = g.integers(-3, 4, size=(n, d)).astype(np.float32)
+    q = g.integers(-3, 4, size=(B, d)).astype(np.float32)
+    c[:, 0] += np.arange(n) % 7  # asymmetric
+    for dtype in (torch.float16, torch.float32):
+        s, r, es, er = run(N, q, c, 5, dtype)
+        assert np.array_equal(s, es)
+        assert np.array_equal(r, er)  # ties are frequent here: exercises lower-row-first
+
+
+def test_ties_duplicates_lower_row_first(N):
+    c = unit_rows(600, 384, 3)
+    c[300:600] = c[0:300]  # every row twice
+    q = c[[5, 17, 299, 0]]
+    s, r, es, er = run(N, q, c, 5, torch.float32)
+    assert np.array_equal(r, er)
+    assert list(r[0][:2]) == [5, 305]
+
+
+def test_ragged_small_and_empty(N):
+    q = unit_rows(4, 384, 1)
+    for n in (0, 1, 3, 5, 255, 256, 257):
+        c = unit_rows(n, 384, 2) if n else np.zeros((0, 384), np.float32)
+        s, r, es, er = run(N, q, c, 5, torch.float16)
+        check(s, r, es, er)
+        assert np.array_equal(r, er)
+
+
+def test_alive_mask_and_row_offset(N):
+    q = unit_rows(40, 768, 1)
+    c = unit_rows(5000, 768, 2)
+    alive = np.random.default_rng(9).random(5000) > 0.3
+    alive[:700] = False
+    s, r, es, er = run(N, q, c, 5, torch.float16, row_offset=1_000_000_007, alive=alive)
+    check(s, r, es, er)
+    assert np.all(alive[r - 1_000_000_007])
+
+
+def test_planted_neighbours(N):
+    """queries = corpus rows + small noise: the known answer is that row"""
+    c = unit_rows(30000, 768, 2)
+    rows = np.arange(0, 30000, 117)[:256]
+    q = c[rows] + 0.02 * unit_rows(256, 768, 7)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    s, r, es, er = run(N, q.astype(np.float32), c, 5, torch.float16)
+    assert np.array_equal(r[:, 0], rows)
+    check(s, r, es, er)
+
+
+def test_merge_topk_device_and_host(N):
+    g = np.random.default_rng(3)
+    G, B, k = 8, 37, 5
+    s = g.standard_normal((G, B, k)).astype(np.float32)
+    s = -np.sort(-s, axis=2)
+    r = g.permutation(G * B * k).reshape(G, B, k).astype(np.int64)
+    s[3, :, 3:] = -np.inf
+    r[3, :, 3:] = -1
+    s[1, 0, 0] = s[2, 0, 0] = 9.0  # tie across shards -> lower global row wins
+    es, er = O.merge_topk(s, r, k)
+    ds, dr = N.merge_topk(torch.from_numpy(s).cuda(), torch.from_numpy(r).cuda(), k)
+    hs, hr = N.merge_topk_host(torch.from_numpy(s), torch.from_numpy(r), k)
+    assert np.array_equal(ds.cpu().numpy(), es) and np.array_equal(dr.cpu().numpy(), er)
+    assert np.array_equal(hs.numpy(), es) and np.array_equal(hr.numpy(), er)
+
+
+def test_bad_arguments_fail_loudly(N):
+    q = torch.zeros((4, 384), dtype=torch.float32, device="cuda")
+    c = torch.zeros((10, 384), dtype=torch.float32, device="cuda")
+    with pytest.raises(N.MMRagNativeError):
+        N.cosine_topk(q, c, 10, 384, 21)
+    with pytest.raises(N.MMRagNativeError):
+        N.cosine_topk(q, c, 11, 384, 5)
+    with pytest.raises(N.MMRagNativeError):
+        N.cosine_topk(q.cpu(), c.cpu(), 10, 384, 5)

@@ -1,0 +1,42 @@
+"""Developer micro-benchmark of mmrag_cosine_topk (not the judged bench.py)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_rag_amd import _native as N
+
+def bench(B, n, d, dtype, k=5, iters=20):
+    ld = N.padded_dim(d, dtype)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    c = torch.empty((n, ld), dtype=dtype, device="cuda")
+    step = 1 << 18
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        x = torch.randn((hi - lo, ld), device="cuda", generator=g)
+        x[:, d:] = 0
+        x /= x.norm(dim=1, keepdim=True)
+        c[lo:hi] = x.to(dtype)
+    q = torch.randn((B, ld), device="cuda", generator=g); q[:, d:] = 0; q /= q.norm(dim=1, keepdim=True); q = q.to(dtype)
+    ws = torch.empty(N.cosine_topk_workspace_bytes(B, n, k) + 16, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        N.cosine_topk(q, c, n, d, k, workspace=ws)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        N.cosine_topk(q, c, n, d, k, workspace=ws)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    byt = n * ld * c.element_size()
+    fl = 2.0 * B * n * d
+    print(f"B={B} n={n} d={d} {dtype} k={k}: {ms*1e3:.1f} us  {byt/ms/1e6:.1f} GB/s  {fl/ms/1e9:.1f} TFLOP/s  {B/ms*1e3:.0f} q/s", flush=True)
+
+if __name__ == "__main__":
+    torch.cuda.init()
+    bench(256, 1_000_000, 768, torch.float16)
+    bench(256, 100_000, 384, torch.float32)
+    bench(1, 1_000_000, 768, torch.float16)
+    bench(32, 1_000_000, 768, torch.float16)
+    bench(128, 1_000_000, 768, torch.float16)
+    bench(256, 125_000, 768, torch.float16)
+    bench(1024, 1_000_000, 768, torch.float16)
+    bench(256, 1_000_000, 768, torch.float16, k=20)
