@@ -74,6 +74,16 @@ int mmrag_cosine_topk(const void *q, const void *corpus, int B, int64_t n, int d
                       float *out_scores, int64_t *out_rows, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* The same search as two stream-ordered phases, so a caller can time, overlap or graph-capture
+ * them separately: phase 1 = the fused GEMM + per-lane selection kernel (reads the corpus once,
+ * leaves candidate lists in `workspace`); phase 2 = the small per-query merge of those lists.
+ * mmrag_cosine_topk(...) == lists(...) then select(...) with the same B, n, k, workspace. */
+int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld,
+                            int dtype, int k, const uint32_t *alive_bits, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int mmrag_cosine_topk_select(int B, int64_t n, int k, int64_t row_offset, const void *workspace,
+                             float *out_scores, int64_t *out_rows, void *stream);
+
 /* Merge G shards' local top-k (layout [G, B, k_in], as produced by an all-gather of
  * mmrag_cosine_topk outputs) into the global top-k [B, k].  Device version (one tiny
  * kernel) and host version (north star: "final host merge"); identical ordering rule.

@@ -40,6 +40,11 @@ def _declare(lib):
     lib.mmrag_cosine_topk.restype = c_int
     lib.mmrag_cosine_topk.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_int,
                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_cosine_topk_lists.restype = c_int
+    lib.mmrag_cosine_topk_lists.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_int,
+                                            c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_cosine_topk_select.restype = c_int
+    lib.mmrag_cosine_topk_select.argtypes = [c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.mmrag_merge_topk.restype = c_int
     lib.mmrag_merge_topk.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.mmrag_merge_topk_host.restype = c_int
@@ -191,3 +196,37 @@ def fetch_rows_f32(corpus: torch.Tensor, rows: torch.Tensor, d: int) -> torch.Te
                                         rows.numel(), d, out.data_ptr(), _stream_ptr(corpus.device))
     _check(st, "mmrag_fetch_rows_f32")
     return out
+
+
+def cosine_topk_lists(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, workspace: torch.Tensor,
+                      alive_bits: Optional[torch.Tensor] = None) -> None:
+    """Phase 1 of cosine_topk: the fused GEMM + selection kernel; candidates stay in `workspace`."""
+    _dev_check(q, corpus, workspace, alive_bits)
+    if q.dtype != corpus.dtype or q.shape[1] != corpus.shape[1] or not q.is_contiguous() or not corpus.is_contiguous():
+        raise MMRagNativeError("cosine_topk_lists: q and corpus must be contiguous and share dtype and padded width")
+    if n > corpus.shape[0]:
+        raise MMRagNativeError(f"cosine_topk_lists: n={n} exceeds corpus capacity {corpus.shape[0]}")
+    B, ld = q.shape
+    with torch.cuda.device(q.device):
+        st = lib().mmrag_cosine_topk_lists(q.data_ptr(), corpus.data_ptr(), B, n, d, ld, _TORCH2DT[q.dtype], k,
+                                           alive_bits.data_ptr() if alive_bits is not None else None,
+                                           workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                           _stream_ptr(q.device))
+    _check(st, "mmrag_cosine_topk_lists")
+
+
+def cosine_topk_select(B: int, n: int, k: int, row_offset: int, workspace: torch.Tensor,
+                       out_scores: Optional[torch.Tensor] = None,
+                       out_rows: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Phase 2 of cosine_topk: merge the candidate lists in `workspace` into [B, k]."""
+    _dev_check(workspace)
+    dev = workspace.device
+    if out_scores is None:
+        out_scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+    if out_rows is None:
+        out_rows = torch.empty((B, k), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().mmrag_cosine_topk_select(B, n, k, row_offset, workspace.data_ptr(), out_scores.data_ptr(),
+                                            out_rows.data_ptr(), _stream_ptr(dev))
+    _check(st, "mmrag_cosine_topk_select")
+    return out_scores, out_rows

@@ -517,30 +517,29 @@ size_t mmrag_cosine_topk_workspace_bytes(int B, int64_t n, int k) {
     return entries * (sizeof(float) + sizeof(int)) + 256;
 }
 
-int mmrag_cosine_topk(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
-                      int k, int64_t row_offset, const uint32_t *alive_bits, float *out_scores,
-                      int64_t *out_rows, void *workspace, size_t workspace_bytes, void *stream) {
+static int check_search_args(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
+                             int k) {
     MMRAG_CHECK_ARG(dtype >= 0 && dtype <= 2, "cosine_topk: bad dtype %d", dtype);
     MMRAG_CHECK_ARG(B > 0, "cosine_topk: B must be positive (got %d)", B);
     MMRAG_CHECK_ARG(k >= 1 && k <= MMRAG_MAX_K, "cosine_topk: k=%d outside 1..%d", k, MMRAG_MAX_K);
     MMRAG_CHECK_ARG(n >= 0 && n < (int64_t)INT_MAX - TM, "cosine_topk: n=%lld out of range", (long long)n);
     MMRAG_CHECK_ARG(d > 0 && ld >= d, "cosine_topk: need 0 < d <= ld (d=%d ld=%lld)", d, (long long)ld);
     const int64_t row_bytes = ld * esize(dtype);
-    MMRAG_CHECK_ARG(row_bytes % SLAB == 0, "cosine_topk: row bytes %lld not a multiple of %d (use mmrag_padded_dim)",
-                    (long long)row_bytes, SLAB);
+    MMRAG_CHECK_ARG(row_bytes % SLAB == 0,
+                    "cosine_topk: row bytes %lld not a multiple of %d (use mmrag_padded_dim)", (long long)row_bytes, SLAB);
     MMRAG_CHECK_ARG(row_bytes * TM < (int64_t)UINT_MAX, "cosine_topk: rows too long");
-    MMRAG_CHECK_ARG(q && out_scores && out_rows, "cosine_topk: null pointer");
+    MMRAG_CHECK_ARG(q, "cosine_topk: null q");
     MMRAG_CHECK_ARG(n == 0 || corpus, "cosine_topk: null corpus");
-    MMRAG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)corpus % 16) == 0, "cosine_topk: q/corpus must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
+    MMRAG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)corpus % 16) == 0,
+                    "cosine_topk: q/corpus must be 16-byte aligned");
+    return MMRAG_OK;
+}
 
-    if (n == 0) {
-        const long long total = (long long)B * k;
-        fill_empty_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(out_scores, (long long *)out_rows, total);
-        MMRAG_CHECK_HIP(hipGetLastError());
-        return MMRAG_OK;
-    }
-
+int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
+                            int k, const uint32_t *alive_bits, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    if (int st = check_search_args(q, corpus, B, n, d, ld, dtype, k)) return st;
+    if (n == 0) return MMRAG_OK;
     const Plan pl = make_plan(B, n, k);
     const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
     const size_t need = entries * (sizeof(float) + sizeof(int));
@@ -558,20 +557,47 @@ int mmrag_cosine_topk(const void *q, const void *corpus, int B, int64_t n, int d
     p.cand_r = (int *)((char *)workspace + entries * sizeof(float));
     p.n = n;
     p.B = B;
-    p.row_bytes = (unsigned)row_bytes;
+    p.row_bytes = (unsigned)(ld * esize(dtype));
     p.n_tiles = pl.n_tiles;
     p.n_lists = pl.n_lists;
-
+    hipStream_t s = (hipStream_t)stream;
     if (dtype == MMRAG_F32) dispatch_main<MMRAG_F32>(pl, p, s);
     else if (dtype == MMRAG_F16) dispatch_main<MMRAG_F16>(pl, p, s);
     else dispatch_main<MMRAG_BF16>(pl, p, s);
     MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
 
+int mmrag_cosine_topk_select(int B, int64_t n, int k, int64_t row_offset, const void *workspace,
+                             float *out_scores, int64_t *out_rows, void *stream) {
+    MMRAG_CHECK_ARG(B > 0 && n >= 0 && k >= 1 && k <= MMRAG_MAX_K, "cosine_topk_select: bad shape");
+    MMRAG_CHECK_ARG(out_scores && out_rows, "cosine_topk_select: null output");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        const long long total = (long long)B * k;
+        fill_empty_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(out_scores, (long long *)out_rows, total);
+        MMRAG_CHECK_HIP(hipGetLastError());
+        return MMRAG_OK;
+    }
+    MMRAG_CHECK_ARG(workspace, "cosine_topk_select: null workspace");
+    const Plan pl = make_plan(B, n, k);
+    const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
+    const float *cand_s = (const float *)workspace;
+    const int *cand_r = (const int *)((const char *)workspace + entries * sizeof(float));
     const long long n_cand = (long long)pl.n_lists * pl.K;
-    launch_merge<int>(pl.K, p.cand_s, p.cand_r, n_cand, n_cand, 0, n_cand, B, k, row_offset, out_scores,
+    launch_merge<int>(pl.K, cand_s, cand_r, n_cand, n_cand, 0, n_cand, B, k, row_offset, out_scores,
                       (long long *)out_rows, s);
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;
+}
+
+int mmrag_cosine_topk(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
+                      int k, int64_t row_offset, const uint32_t *alive_bits, float *out_scores,
+                      int64_t *out_rows, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int st = mmrag_cosine_topk_lists(q, corpus, B, n, d, ld, dtype, k, alive_bits, workspace, workspace_bytes,
+                                         stream))
+        return st;
+    return mmrag_cosine_topk_select(B, n, k, row_offset, workspace, out_scores, out_rows, stream);
 }
 
 int mmrag_merge_topk(const float *scores, const int64_t *rows, int G, int B, int k_in, int k,

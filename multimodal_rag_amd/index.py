@@ -1,0 +1,258 @@
+"""Device-resident vector collection: what `chromadb`'s collection is to the reference.
+
+Replaces the engine calls made by app/utils/embedder.py:
+    collection.add(embeddings, documents, metadatas, ids)          :518
+    collection.query(query_embeddings, n_results, where, include)  :596-601, :900-905
+    collection.get(where|ids, include)                             :632-635, :887-891
+    collection.delete(ids)                                         :639-642
+    collection.count()                                             :700
+The vectors live in one [capacity, ld] matrix in HBM (fp16 by default, rows padded to the
+kernel's 128-byte slabs); ids / documents / metadata stay in host tables indexed by row, as
+SURVEY.md section 8b "Ownership" lays out.  Search is exact (fused MFMA GEMM + top-k in
+libmmrag.so), distance = 1 - cos (the committed collection's hnsw:space=cosine).
+
+No arithmetic happens in this file: torch provides device buffers and copies only.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+from typing import Any, Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+
+logger = logging.getLogger(__name__)
+
+
+# --------------------------------------------------------------------------------------------
+# `where` filters (the subset of Chroma's grammar that is expressible on flat metadata)
+# --------------------------------------------------------------------------------------------
+_CMP: Dict[str, Callable[[Any, Any], bool]] = {
+    "$eq": lambda a, b: a == b,
+    "$ne": lambda a, b: a != b,
+    "$gt": lambda a, b: a is not None and a > b,
+    "$gte": lambda a, b: a is not None and a >= b,
+    "$lt": lambda a, b: a is not None and a < b,
+    "$lte": lambda a, b: a is not None and a <= b,
+    "$in": lambda a, b: a in b,
+    "$nin": lambda a, b: a not in b,
+}
+
+
+def match_where(meta: Dict[str, Any], where: Optional[Dict[str, Any]]) -> bool:
+    if not where:
+        return True
+    for key, cond in where.items():
+        if key == "$and":
+            if not all(match_where(meta, w) for w in cond):
+                return False
+        elif key == "$or":
+            if not any(match_where(meta, w) for w in cond):
+                return False
+        elif isinstance(cond, dict):
+            for op, val in cond.items():
+                if op not in _CMP:
+                    raise ValueError(f"unsupported where operator {op!r}")
+                if not _CMP[op](meta.get(key), val):
+                    return False
+        else:
+            if meta.get(key) != cond:
+                return False
+    return True
+
+
+class VectorIndex:
+    """One shard of the corpus matrix on one GPU plus its host-side row tables."""
+
+    def __init__(self, dim: int, dtype: torch.dtype = torch.float16, device: str = "cuda:0",
+                 capacity: int = 4096, name: str = "multimodal_rag",
+                 metadata: Optional[Dict[str, Any]] = None):
+        if dtype not in (torch.float16, torch.float32, torch.bfloat16):
+            raise ValueError(f"unsupported storage dtype {dtype}")
+        _native.lib()  # fail loudly if the HIP library is absent
+        self.name = name
+        self.metadata = dict(metadata or {})
+        self.dim = int(dim)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.ld = _native.padded_dim(self.dim, dtype)
+        self._matrix = torch.zeros((max(int(capacity), 256), self.ld), dtype=dtype, device=self.device)
+        self._n = 0
+        self._ids: List[str] = []
+        self._documents: List[Optional[str]] = []
+        self._metadatas: List[Dict[str, Any]] = []
+        self._row_of: Dict[str, int] = {}
+        self._lock = threading.RLock()
+
+    # ------------------------------------------------------------------ storage ----------
+    @property
+    def matrix(self) -> torch.Tensor:
+        return self._matrix
+
+    def count(self) -> int:
+        return self._n
+
+    def _reserve(self, rows: int):
+        cap = self._matrix.shape[0]
+        if rows <= cap:
+            return
+        new_cap = max(rows, cap * 2)
+        grown = torch.zeros((new_cap, self.ld), dtype=self.dtype, device=self.device)
+        grown[: self._n].copy_(self._matrix[: self._n])
+        self._matrix = grown
+
+    def _to_device_f32(self, x) -> torch.Tensor:
+        if isinstance(x, torch.Tensor):
+            t = x
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        if t.dim() != 2 or t.shape[1] != self.dim:
+            raise ValueError(f"embedding dimension {tuple(t.shape)} does not match collection dimensionality {self.dim}")
+        return t.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
+
+    def _pack_queries(self, q) -> torch.Tensor:
+        """float32 [B, d] -> storage dtype [B, ld] with zero pad columns (device-side cast kernel)."""
+        qf = self._to_device_f32(q)
+        packed = torch.empty((qf.shape[0], self.ld), dtype=self.dtype, device=self.device)
+        _native.append_rows(packed, 0, qf, self.dim)
+        return packed
+
+    # ------------------------------------------------------------------ collection API ----
+    def add(self, embeddings, documents: Optional[Sequence[Optional[str]]] = None,
+            metadatas: Optional[Sequence[Dict[str, Any]]] = None, ids: Optional[Sequence[str]] = None):
+        if ids is None:
+            raise ValueError("ids are required")
+        emb = self._to_device_f32(embeddings)
+        m = emb.shape[0]
+        if len(ids) != m:
+            raise ValueError(f"{len(ids)} ids for {m} embeddings")
+        documents = list(documents) if documents is not None else [None] * m
+        metadatas = [dict(x) if x else {} for x in metadatas] if metadatas is not None else [{} for _ in range(m)]
+        if len(documents) != m or len(metadatas) != m:
+            raise ValueError("documents / metadatas length mismatch")
+        with self._lock:
+            fresh = [i for i, s in enumerate(ids) if s not in self._row_of]
+            seen = set()
+            keep = []
+            for i in fresh:
+                if ids[i] not in seen:
+                    seen.add(ids[i])
+                    keep.append(i)
+            if len(keep) != m:
+                logger.warning("Add of existing embedding ID ignored for %d of %d items", m - len(keep), m)
+                if not keep:
+                    return
+                emb = emb[torch.tensor(keep, device=self.device)].contiguous()
+            self._reserve(self._n + len(keep))
+            _native.append_rows(self._matrix, self._n, emb, self.dim)
+            for j, i in enumerate(keep):
+                self._row_of[ids[i]] = self._n + j
+                self._ids.append(ids[i])
+                self._documents.append(documents[i])
+                self._metadatas.append(metadatas[i])
+            self._n += len(keep)
+
+    def add_rows_device(self, rows_packed: torch.Tensor, documents, metadatas, ids):
+        """Append rows that are already in storage layout [m, ld] (bulk loads, benchmarks)."""
+        m = rows_packed.shape[0]
+        with self._lock:
+            self._reserve(self._n + m)
+            self._matrix[self._n: self._n + m].copy_(rows_packed)
+            for i in range(m):
+                self._row_of[ids[i]] = self._n + i
+            self._ids.extend(ids)
+            self._documents.extend(documents if documents is not None else [None] * m)
+            self._metadatas.extend(metadatas if metadatas is not None else [{} for _ in range(m)])
+            self._n += m
+
+    def _alive_bits(self, where: Optional[Dict[str, Any]]) -> Optional[torch.Tensor]:
+        if not where:
+            return None
+        words = np.zeros((self._n + 31) // 32 + 8, dtype=np.uint32)
+        idx = np.fromiter((i for i in range(self._n) if match_where(self._metadatas[i], where)), dtype=np.int64)
+        if idx.size:
+            np.bitwise_or.at(words, idx // 32, np.uint32(1) << (idx % 32).astype(np.uint32))
+        return torch.from_numpy(words.view(np.int32)).to(self.device)
+
+    def search(self, query_embeddings, n_results: int, where: Optional[Dict[str, Any]] = None):
+        """Raw device search: (scores [B, k] float32 desc, rows [B, k] int64, -1 = none)."""
+        if n_results < 1 or n_results > _native.MAX_K:
+            raise ValueError(f"n_results must be in 1..{_native.MAX_K}")
+        with self._lock:
+            q = self._pack_queries(query_embeddings)
+            bits = self._alive_bits(where)
+            return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
+
+    def query(self, query_embeddings, n_results: int = 10, where: Optional[Dict[str, Any]] = None,
+              include: Sequence[str] = ("metadatas", "documents", "distances")) -> Dict[str, Any]:
+        """Chroma-shaped result: lists of lists, ascending distance = 1 - cos, at most count() hits."""
+        with self._lock:
+            scores, rows = self.search(query_embeddings, n_results, where)
+            scores = scores.cpu().numpy()
+            rows = rows.cpu().numpy()
+            out: Dict[str, Any] = {"ids": []}
+            for key in ("distances", "metadatas", "documents", "embeddings"):
+                out[key] = [] if key in include else None
+            for b in range(rows.shape[0]):
+                hit = [int(r) for r in rows[b] if r >= 0]
+                out["ids"].append([self._ids[r] for r in hit])
+                if "distances" in include:
+                    out["distances"].append([float(np.float32(1.0) - scores[b, j]) for j in range(len(hit))])
+                if "metadatas" in include:
+                    out["metadatas"].append([dict(self._metadatas[r]) for r in hit])
+                if "documents" in include:
+                    out["documents"].append([self._documents[r] for r in hit])
+                if "embeddings" in include:
+                    out["embeddings"].append(self._fetch(hit))
+            return out
+
+    def _fetch(self, rows: List[int]) -> List[List[float]]:
+        if not rows:
+            return []
+        t = _native.fetch_rows_f32(self._matrix, torch.tensor(rows, dtype=torch.int64, device=self.device), self.dim)
+        return t.cpu().numpy().tolist()
+
+    def get(self, ids: Optional[Sequence[str]] = None, where: Optional[Dict[str, Any]] = None,
+            include: Sequence[str] = ("metadatas", "documents")) -> Dict[str, Any]:
+        with self._lock:
+            if ids is not None:
+                rows = [self._row_of[i] for i in ids if i in self._row_of]
+                rows = [r for r in rows if match_where(self._metadatas[r], where)]
+            else:
+                rows = [r for r in range(self._n) if match_where(self._metadatas[r], where)]
+            out: Dict[str, Any] = {"ids": [self._ids[r] for r in rows]}
+            out["metadatas"] = [dict(self._metadatas[r]) for r in rows] if "metadatas" in include else None
+            out["documents"] = [self._documents[r] for r in rows] if "documents" in include else None
+            out["embeddings"] = self._fetch(rows) if "embeddings" in include else None
+            return out
+
+    def delete(self, ids: Optional[Sequence[str]] = None, where: Optional[Dict[str, Any]] = None) -> List[str]:
+        """Remove rows and compact the matrix (stable: survivors keep their insertion order, so
+        the lower-row-first tie rule keeps meaning 'earlier insert first')."""
+        with self._lock:
+            victims = set(self.get(ids=ids, where=where, include=())["ids"])
+            if not victims:
+                return []
+            keep = [r for r in range(self._n) if self._ids[r] not in victims]
+            if keep:
+                dst = torch.zeros_like(self._matrix)
+                _native.gather_rows(dst, self._matrix, torch.tensor(keep, dtype=torch.int64, device=self.device))
+                self._matrix = dst
+            else:
+                self._matrix.zero_()
+            self._ids = [self._ids[r] for r in keep]
+            self._documents = [self._documents[r] for r in keep]
+            self._metadatas = [self._metadatas[r] for r in keep]
+            self._row_of = {s: i for i, s in enumerate(self._ids)}
+            self._n = len(keep)
+            return sorted(victims)
+
+    def reset(self):
+        with self._lock:
+            self._n = 0
+            self._ids, self._documents, self._metadatas, self._row_of = [], [], [], {}
