@@ -113,6 +113,66 @@ int mmrag_gather_rows(void *dst, const void *src, int64_t ld, int dtype,
 int mmrag_fetch_rows_f32(const void *corpus, int64_t ld, int dtype, const int64_t *rows,
                          int64_t m, int d, float *out, void *stream);
 
+
+/* ---------------------------------------------------------------------------------------
+ * Embed.  Replaces SentenceTransformer.encode(texts, batch_size=len(texts),
+ * convert_to_numpy=True, normalize_embeddings=True)   app/utils/embedder.py:397-403
+ * (tokenisation stays on the host; these entry points take token ids).
+ * fp16 weights/activations, fp32 accumulate and fp32 LayerNorm / softmax / pooling statistics.
+ * Sequences are PACKED: token t of sequence b is row cu_seqlens[b] + t; no padded tokens.
+ * ------------------------------------------------------------------------------------- */
+#define MMRAG_ACT_NONE 0
+#define MMRAG_ACT_GELU 1       /* erf GELU (BERT) */
+#define MMRAG_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x) (CLIP) */
+
+#define MMRAG_ARCH_BERT 0  /* post-LN blocks, learned absolute positions, token-type 0, embedding LN */
+#define MMRAG_ARCH_PRELN 1 /* pre-LN blocks (CLIP towers), final LN, bias-free projection */
+
+#define MMRAG_POOL_MEAN 0  /* masked mean over the sequence's tokens (all-MiniLM-L6-v2) */
+#define MMRAG_POOL_FIRST 1 /* first token: [CLS] (bge-base-en-v1.5, CLIP vision) */
+#define MMRAG_POOL_SELECT 2 /* token sel[b] of each sequence (CLIP text: EOS position) */
+
+typedef struct mmrag_encoder_desc {
+    int32_t arch;
+    int32_t n_layers, hidden, n_heads, intermediate, vocab, max_pos;
+    int32_t pool, act, causal, normalize;
+    int32_t out_dim; /* == hidden for BERT; projection width for MMRAG_ARCH_PRELN */
+    float ln_eps;
+} mmrag_encoder_desc;
+
+/* Weight table `w` (device pointers; matrices fp16 stored [out_features][in_features], i.e.
+ * the transpose of a torch Linear's .weight.T -- exactly nn.Linear.weight; biases and LayerNorm
+ * parameters fp32):
+ *   w[0] tok_emb [vocab,H]  w[1] pos_emb [max_pos,H]  w[2] type_emb row 0 [H] (NULL if none)
+ *   w[3], w[4] embedding LayerNorm gamma, beta (both NULL for MMRAG_ARCH_PRELN text)
+ *   then per layer l, at w[5 + 12 l ...]:
+ *     wqkv [3H,H], bqkv [3H], wo [H,H], bo [H], ln1_g, ln1_b, w1 [I,H], b1 [I], w2 [H,I], b2 [H],
+ *     ln2_g, ln2_b           (ln1 = attention LN, ln2 = MLP LN; pre- or post- per arch)
+ *   MMRAG_ARCH_PRELN tail at w[5 + 12 L ...]: final_ln_g, final_ln_b, proj [out_dim, H]
+ *
+ *   ids, pos_ids  dev [T] int32 packed token ids / position ids
+ *   cu_seqlens    dev [B+1] int32 row offsets, cu_seqlens[B] == T
+ *   sel           dev [B] int32 (MMRAG_POOL_SELECT only)
+ *   out           dev [B, out_dim] float32, L2-normalised when desc.normalize != 0 */
+size_t mmrag_encoder_workspace_bytes(const mmrag_encoder_desc *desc, int64_t T, int B);
+int mmrag_encoder_forward(const mmrag_encoder_desc *desc, const void *const *w, const int32_t *ids,
+                          const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel,
+                          int64_t T, int B, int max_len, float *out, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* The encoder's building blocks, exported so each kernel can be parity-tested on its own. */
+int mmrag_linear_f16(const void *x, int64_t M, int K, const void *wt, int N, const float *bias, int act,
+                     const void *resid, void *out, void *stream);
+int mmrag_layernorm_f16(const void *x, void *out, const float *gamma, const float *beta, int64_t T, int H,
+                        float eps, void *stream);
+int mmrag_embed_ln_f16(const int32_t *ids, const int32_t *pos_ids, const void *tok, const void *pos,
+                       const void *type0, const float *gamma, const float *beta, void *out, int64_t T,
+                       int H, int vocab, int max_pos, float eps, void *stream);
+int mmrag_attention_f16(const void *qkv, const int32_t *cu_seqlens, void *ctx, int B, int max_len, int H,
+                        int n_heads, int causal, void *stream);
+int mmrag_pool_normalize_f16(const void *x, const int32_t *cu_seqlens, const int32_t *sel, float *out,
+                             int B, int H, int pool, int normalize, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

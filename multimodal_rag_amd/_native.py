@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from typing import Optional, Tuple
 
 import torch
@@ -55,12 +55,24 @@ def _declare(lib):
     lib.mmrag_gather_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
     lib.mmrag_fetch_rows_f32.restype = c_int
     lib.mmrag_fetch_rows_f32.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]
-    if hasattr(lib, "mmrag_encoder_workspace_bytes"):
-        lib.mmrag_encoder_workspace_bytes.restype = c_size_t
-        lib.mmrag_encoder_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
-        lib.mmrag_encoder_forward.restype = c_int
-        lib.mmrag_encoder_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                              c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_encoder_workspace_bytes.restype = c_size_t
+    lib.mmrag_encoder_workspace_bytes.argtypes = [c_void_p, c_int64, c_int]
+    lib.mmrag_encoder_forward.restype = c_int
+    lib.mmrag_encoder_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                          c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_linear_f16.restype = c_int
+    lib.mmrag_linear_f16.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p]
+    lib.mmrag_layernorm_f16.restype = c_int
+    lib.mmrag_layernorm_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]
+    lib.mmrag_embed_ln_f16.restype = c_int
+    lib.mmrag_embed_ln_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_int, c_int, c_int, c_float, c_void_p]
+    lib.mmrag_attention_f16.restype = c_int
+    lib.mmrag_attention_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.mmrag_pool_normalize_f16.restype = c_int
+    lib.mmrag_pool_normalize_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_void_p]
 
 
 def lib():
@@ -230,3 +242,112 @@ def cosine_topk_select(B: int, n: int, k: int, row_offset: int, workspace: torch
                                             out_rows.data_ptr(), _stream_ptr(dev))
     _check(st, "mmrag_cosine_topk_select")
     return out_scores, out_rows
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder building blocks (fp16 tensors on the device)
+# ----------------------------------------------------------------------------------------------
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
+ARCH_BERT, ARCH_PRELN = 0, 1
+POOL_MEAN, POOL_FIRST, POOL_SELECT = 0, 1, 2
+
+
+class EncoderDesc(ctypes.Structure):
+    """mirror of `mmrag_encoder_desc` (include/mmrag.h)"""
+    _fields_ = [("arch", c_int32), ("n_layers", c_int32), ("hidden", c_int32), ("n_heads", c_int32),
+                ("intermediate", c_int32), ("vocab", c_int32), ("max_pos", c_int32), ("pool", c_int32),
+                ("act", c_int32), ("causal", c_int32), ("normalize", c_int32), ("out_dim", c_int32),
+                ("ln_eps", c_float)]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return t.data_ptr() if t is not None else None
+
+
+def linear_f16(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+               resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = act(x[M, K] @ wt[N, K].T + bias) (+ resid)"""
+    _dev_check(x, wt, bias, resid, out)
+    M, K = x.shape
+    Nf = wt.shape[0]
+    if x.dtype != torch.float16 or wt.dtype != torch.float16 or wt.shape[1] != K:
+        raise MMRagNativeError("linear_f16: x [M,K] and wt [N,K] must be fp16 with matching K")
+    if out is None:
+        out = torch.empty((M, Nf), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib().mmrag_linear_f16(x.data_ptr(), M, K, wt.data_ptr(), Nf, _ptr(bias), act, _ptr(resid),
+                                    out.data_ptr(), _stream_ptr(x.device))
+    _check(st, "mmrag_linear_f16")
+    return out
+
+
+def layernorm_f16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    _dev_check(x, gamma, beta)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = lib().mmrag_layernorm_f16(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.shape[0],
+                                       x.shape[1], eps, _stream_ptr(x.device))
+    _check(st, "mmrag_layernorm_f16")
+    return out
+
+
+def embed_ln_f16(ids, pos_ids, tok, pos, type0, gamma, beta, eps: float) -> torch.Tensor:
+    _dev_check(ids, pos_ids, tok, pos, type0, gamma, beta)
+    T, H = ids.numel(), tok.shape[1]
+    out = torch.empty((T, H), dtype=torch.float16, device=tok.device)
+    with torch.cuda.device(tok.device):
+        st = lib().mmrag_embed_ln_f16(ids.data_ptr(), pos_ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), _ptr(type0),
+                                      _ptr(gamma), _ptr(beta), out.data_ptr(), T, H, tok.shape[0], pos.shape[0], eps,
+                                      _stream_ptr(tok.device))
+    _check(st, "mmrag_embed_ln_f16")
+    return out
+
+
+def attention_f16(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, n_heads: int,
+                  causal: bool = False) -> torch.Tensor:
+    _dev_check(qkv, cu_seqlens)
+    T, H3 = qkv.shape
+    H = H3 // 3
+    ctx = torch.empty((T, H), dtype=torch.float16, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        st = lib().mmrag_attention_f16(qkv.data_ptr(), cu_seqlens.data_ptr(), ctx.data_ptr(), cu_seqlens.numel() - 1,
+                                       max_len, H, n_heads, int(causal), _stream_ptr(qkv.device))
+    _check(st, "mmrag_attention_f16")
+    return ctx
+
+
+def pool_normalize_f16(x: torch.Tensor, cu_seqlens: torch.Tensor, pool: int, normalize: bool = True,
+                       sel: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_check(x, cu_seqlens, sel)
+    B, H = cu_seqlens.numel() - 1, x.shape[1]
+    out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib().mmrag_pool_normalize_f16(x.data_ptr(), cu_seqlens.data_ptr(), _ptr(sel), out.data_ptr(), B, H, pool,
+                                            int(normalize), _stream_ptr(x.device))
+    _check(st, "mmrag_pool_normalize_f16")
+    return out
+
+
+def encoder_workspace_bytes(desc: EncoderDesc, T: int, B: int) -> int:
+    return int(lib().mmrag_encoder_workspace_bytes(ctypes.byref(desc), T, B))
+
+
+def encoder_forward(desc: EncoderDesc, weight_ptrs, ids: torch.Tensor, pos_ids: torch.Tensor,
+                    cu_seqlens: torch.Tensor, max_len: int, sel: Optional[torch.Tensor] = None,
+                    workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One encoder pass over packed token ids -> [B, out_dim] float32.  `weight_ptrs` is a ctypes
+    array of c_void_p in the order include/mmrag.h documents (see encoder.DeviceEncoder)."""
+    _dev_check(ids, pos_ids, cu_seqlens, sel, workspace, out)
+    T, B = ids.numel(), cu_seqlens.numel() - 1
+    need = encoder_workspace_bytes(desc, T, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=ids.device)
+    if out is None:
+        out = torch.empty((B, desc.out_dim), dtype=torch.float32, device=ids.device)
+    with torch.cuda.device(ids.device):
+        st = lib().mmrag_encoder_forward(ctypes.byref(desc), weight_ptrs, ids.data_ptr(), pos_ids.data_ptr(),
+                                         cu_seqlens.data_ptr(), _ptr(sel), T, B, max_len, out.data_ptr(),
+                                         workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                         _stream_ptr(ids.device))
+    _check(st, "mmrag_encoder_forward")
+    return out

@@ -1,0 +1,744 @@
+// Transformer encoder forward for gfx950 (MI355X): the embed half of the hot path.
+//
+// Replaces SentenceTransformer.encode(texts, normalize_embeddings=True)
+// (reference call site app/utils/embedder.py:397-403; model all-MiniLM-L6-v2 / bge-base /
+// CLIP towers per config.py:102-106).  fp16 weights and activations, fp32 accumulation and
+// fp32 LayerNorm / softmax / pooling statistics.  Sequences are packed (no padded tokens):
+// x is [T, H] with sequence b owning rows cu_seqlens[b] .. cu_seqlens[b+1].
+//
+// Kernels
+//   embed_ln_kernel   gather tok+pos(+type) rows, LayerNorm                    (HBM-bound)
+//   linear_kernel     out = act(x . Wt^T + bias) (+ residual); MFMA 32x32x16 f16, LDS-DMA
+//                     slab ring shared with the search kernel (tile_dma.h); epilogue
+//                     transposes the tile through LDS for whole-row 512-byte stores  (MFMA-bound)
+//   attention_kernel  flash-style, per (sequence, head, 128-query tile): S^T = K.Q^T so the
+//                     query sits on the lane and softmax state is lane-local; P feeds the
+//                     P.V MFMA straight from the accumulator registers; V is transposed
+//                     while it is staged into LDS                               (MFMA-bound)
+//   layernorm_kernel  row LayerNorm (residual already added by linear_kernel)   (HBM-bound)
+//   pool_norm_kernel  masked mean / CLS / last-token pooling (+ LayerNorm for CLIP), L2 norm
+#include "mmrag_internal.h"
+#include "tile_dma.h"
+
+#include <limits.h>
+
+using namespace mmrag;
+
+namespace mmrag_impl {
+
+constexpr float NEG_INF_F = -__builtin_inff();
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ inline float2 h2f(half2_t t) { return make_float2((float)t[0], (float)t[1]); }
+__device__ inline half2_t f2h(float a, float b) {
+    half2_t r;
+    r[0] = (_Float16)a;
+    r[1] = (_Float16)b;
+    return r;
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ inline float act_apply(float x, int act) {
+    if (act == MMRAG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (act == MMRAG_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over rows of H fp16 (one wave per row, fp32 statistics)
+// ---------------------------------------------------------------------------------------------
+template <int MAXV>  // MAXV half2 per lane: H <= 128 * MAXV
+__device__ inline void ln_row(const _Float16 *src, _Float16 *dst, const float *g, const float *b, int H, float eps,
+                              int lane, const _Float16 *add1 = nullptr, const _Float16 *add2 = nullptr) {
+    float2 v[MAXV];
+    const int n2 = H >> 1;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = make_float2(0.f, 0.f);
+        if (c < n2) {
+            const half2_t t = ((const half2_t *)src)[c];
+            v[i] = h2f(t);
+            if (add1) {
+                const float2 a = h2f(((const half2_t *)add1)[c]);
+                v[i].x += a.x;
+                v[i].y += a.y;
+            }
+            if (add2) {
+                const float2 a = h2f(((const half2_t *)add2)[c]);
+                v[i].x += a.x;
+                v[i].y += a.y;
+            }
+            s += v[i].x + v[i].y;
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < n2) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean;
+            q += dx * dx + dy * dy;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < n2) {
+            const float2 gg = ((const float2 *)g)[c];
+            const float2 bb = ((const float2 *)b)[c];
+            ((half2_t *)dst)[c] = f2h((v[i].x - mean) * rstd * gg.x + bb.x,
+                                                    (v[i].y - mean) * rstd * gg.y + bb.y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ out,
+                                                         const float *__restrict__ g, const float *__restrict__ b,
+                                                         int T, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    ln_row<8>(x + (size_t)row * H, out + (size_t)row * H, g, b, H, eps, lane);
+}
+
+// out[t] = LN(tok[ids[t]] + pos[pos_ids[t]] (+ type[0]))      (BERT embeddings, post-LN)
+// with g == nullptr: plain sum (CLIP text: no embedding LayerNorm)
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int *__restrict__ ids, const int *__restrict__ pos_ids,
+                                                        const _Float16 *__restrict__ tok,
+                                                        const _Float16 *__restrict__ pos,
+                                                        const _Float16 *__restrict__ type0,
+                                                        const float *__restrict__ g, const float *__restrict__ b,
+                                                        _Float16 *__restrict__ out, int T, int H, int vocab,
+                                                        int max_pos, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    int id = ids[row];
+    int ps = pos_ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+    const _Float16 *a = tok + (size_t)id * H;
+    const _Float16 *p2 = pos + (size_t)ps * H;
+    if (g != nullptr) {
+        ln_row<8>(a, out + (size_t)row * H, g, b, H, eps, lane, p2, type0);
+    } else {
+        for (int c = lane; c < (H >> 1); c += 64) {
+            float2 v = h2f(((const half2_t *)a)[c]);
+            const float2 w = h2f(((const half2_t *)p2)[c]);
+            ((half2_t *)(out + (size_t)row * H))[c] = f2h(v.x + w.x, v.y + w.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear: out[M, N] = act(x[M, K] . wt[N, K]^T + bias[N]) (+ resid[M, N])
+// MFMA orientation: D[feature][token]: features in the accumulator registers (MFMA A = weight
+// rows), tokens on the lanes (MFMA B = activation rows).
+// ---------------------------------------------------------------------------------------------
+struct LinearParams {
+    const char *x;
+    const char *wt;
+    const float *bias;
+    const _Float16 *resid;
+    _Float16 *out;
+    int M, N, K;
+    int act;
+};
+
+template <int BF, int BT, int WF, int WT, int NSTAGE>
+__global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(const LinearParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WF * WT;
+    constexpr int RF = BF / (32 * WF);
+    constexpr int RT = BT / (32 * WT);
+    constexpr int STAGE = (BF + BT) * SLAB;
+    constexpr int PIECES = (BF + BT) / 8;
+    constexpr int PW = PIECES / NW;  // DMA pieces per wave per ring item
+    constexpr int W_PIECES = BF / 8;
+    constexpr int STG_ROW = BF * 2 + 8;  // staged C tile: [token][feature] fp16, padded rows
+    constexpr int STG_BYTES = BT * STG_ROW;
+    constexpr int RING_BYTES = NSTAGE * STAGE;
+    constexpr int LDS_BYTES = RING_BYTES > STG_BYTES ? RING_BYTES : STG_BYTES;
+    static_assert(PIECES % NW == 0 && W_PIECES % PW == 0, "piece split");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wf = wave / WT;
+    const int wt_ = wave % WT;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+
+    const int tiles_f = (p.N + BF - 1) / BF;
+    const int tile_f = blockIdx.x % tiles_f;
+    const int tile_t = blockIdx.x / tiles_f;
+    const int f0 = tile_f * BF;
+    const int t0 = tile_t * BT;
+    const unsigned RB = (unsigned)p.K * 2u;
+    const int nk = (int)(RB / SLAB);
+
+    const int f_left = p.N - f0, t_left = p.M - t0;
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        make_rsrc(p.wt + (size_t)f0 * RB, (unsigned)((f_left < BF ? f_left : BF) * (long long)RB));
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        make_rsrc(p.x + (size_t)t0 * RB, (unsigned)((t_left < BT ? t_left : BT) * (long long)RB));
+
+    unsigned src_off[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int piece = wave * PW + i;
+        src_off[i] = dma_src_offset(piece < W_PIECES ? piece : piece - W_PIECES, lane, RB);
+    }
+    auto issue = [&](int item) {
+        char *st = smem + (item % NSTAGE) * STAGE;
+        const unsigned koff = (unsigned)item * SLAB;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int piece = wave * PW + i;
+            if (piece < W_PIECES)
+                dma_piece(rsrc_w, st, piece, src_off[i] + koff);
+            else
+                dma_piece(rsrc_x, st + BF * SLAB, piece - W_PIECES, src_off[i] + koff);
+        }
+    };
+
+    f32x16_t acc[RF][RT];
+#pragma unroll
+    for (int a = 0; a < RF; ++a)
+#pragma unroll
+        for (int b = 0; b < RT; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.0f;
+
+    const int sw = (r32 >> 1) & 7;
+    const int a_base = (wf * RF * 32 + r32) * SLAB;
+    const int b_base = BF * SLAB + (wt_ * RT * 32 + r32) * SLAB;
+
+    int issued = 0;
+    for (; issued < NSTAGE - 1 && issued < nk; ++issued) issue(issued);
+    for (int it = 0; it < nk; ++it) {
+        wait_items<PW, NSTAGE - 2>(issued - it - 1);
+        __builtin_amdgcn_s_barrier();
+        if (issued < nk) {
+            issue(issued);
+            ++issued;
+        }
+        const char *st = smem + (it % NSTAGE) * STAGE;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int off = ((2 * m + h) ^ sw) * 16;
+            half8_t bt[RT];
+#pragma unroll
+            for (int b = 0; b < RT; ++b) bt[b] = *(const half8_t *)(st + b_base + b * (32 * SLAB) + off);
+#pragma unroll
+            for (int a = 0; a < RF; ++a) {
+                const half8_t af = *(const half8_t *)(st + a_base + a * (32 * SLAB) + off);
+#pragma unroll
+                for (int b = 0; b < RT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bt[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue phase 1: bias + activation in fp32, stage the tile as [token][feature] fp16
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+#pragma unroll
+    for (int a = 0; a < RF; ++a) {
+        const int fl = wf * RF * 32 + a * 32 + 4 * h;  // local feature of register group 0
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = fl + 8 * g;  // features f .. f+3 live in registers 4g .. 4g+3
+            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && f0 + f + 3 < p.N) {
+                const float4 bv = *(const float4 *)(p.bias + f0 + f);
+                bias4[0] = bv.x, bias4[1] = bv.y, bias4[2] = bv.z, bias4[3] = bv.w;
+            }
+#pragma unroll
+            for (int b = 0; b < RT; ++b) {
+                const int tl = wt_ * RT * 32 + b * 32 + r32;
+                half4_t o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply(acc[a][b][4 * g + i] + bias4[i], p.act);
+                *(half4_t *)(smem + tl * STG_ROW + f * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: whole-row stores (8 bytes per lane, BF*2 contiguous bytes per row)
+    constexpr int LANES_PER_ROW = BF / 4;
+    constexpr int ROWS_PER_INSTR = 64 / LANES_PER_ROW;
+    const int sub = lane / LANES_PER_ROW;
+    const int col = (lane % LANES_PER_ROW) * 4;
+    for (int r = wave * ROWS_PER_INSTR + sub; r < BT; r += NW * ROWS_PER_INSTR) {
+        const int t = t0 + r;
+        const int f = f0 + col;
+        if (t < p.M && f < p.N) {
+            half4_t v = *(const half4_t *)(smem + r * STG_ROW + col * 2);
+            if (p.resid != nullptr) {
+                const half4_t rv = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (_Float16)((float)v[i] + (float)rv[i]);
+            }
+            *(half4_t *)(p.out + (size_t)t * p.N + f) = v;
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention (packed sequences): ctx[t, head*DH + d] = softmax(Q K^T * scale + mask) V
+// qkv is [T, 3H] fp16 (Q | K | V column blocks).  One workgroup = (128-query tile, head, seq),
+// 4 waves x 32 queries; keys are consumed in tiles of 64.
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256, 1) void attention_kernel(const _Float16 *__restrict__ qkv,
+                                                            const int *__restrict__ cu_seqlens,
+                                                            _Float16 *__restrict__ ctx, int H, float scale,
+                                                            int causal) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(DH == 32 || DH == 64, "head dim");
+    constexpr int KT = 64;                 // keys per tile
+    constexpr int CH = DH / 8;             // 16-byte chunks per K row
+    constexpr int KROW = DH * 2;           // K tile row bytes
+    constexpr int VROW = KT * 2 + 8;       // V^T tile row bytes (padded: conflict-free b64 reads)
+    constexpr int K_BYTES = KT * KROW;
+    constexpr int V_BYTES = DH * VROW;
+    constexpr int NQK = DH / 16;           // MFMA k-steps for Q.K^T
+    constexpr int NDB = DH / 32;           // 32-row blocks of O^T
+    __shared__ __attribute__((aligned(16))) char smem[2 * (K_BYTES + V_BYTES)];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int hh = lane >> 5;
+    const int head = blockIdx.y;
+    const int seq0 = cu_seqlens[blockIdx.z];
+    const int len = cu_seqlens[blockIdx.z + 1] - seq0;
+    const int q_tile0 = blockIdx.x * 128;
+    if (q_tile0 >= len) return;
+    const int ld = 3 * H;
+    const _Float16 *Qp = qkv + (size_t)seq0 * ld + head * DH;
+    const _Float16 *Kp = Qp + H;
+    const _Float16 *Vp = Qp + 2 * H;
+
+    // this lane's query row (both half-waves hold the same 32 queries)
+    const int qi = q_tile0 + wave * 32 + r32;
+    half8_t qf[NQK];
+#pragma unroll
+    for (int ks = 0; ks < NQK; ++ks) {
+        if (qi < len)
+            qf[ks] = *(const half8_t *)(Qp + (size_t)qi * ld + ks * 16 + hh * 8);
+        else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[ks][i] = (_Float16)0.f;
+    }
+
+    const int kv_end = causal ? ((q_tile0 + 128 < len) ? q_tile0 + 128 : len) : len;
+    const int n_tiles = (kv_end + KT - 1) / KT;
+
+    // staging assignment.  K: 16-byte chunk (key, c) per thread-iteration, coalesced.
+    // V: lane = key, so the transposed 2-byte LDS writes of a wave are contiguous.
+    constexpr int K_ITERS = (KT * CH) / 256 > 0 ? (KT * CH) / 256 : 1;
+    constexpr int V_ITERS = CH / 4 > 0 ? CH / 4 : 1;  // d-chunks per wave
+    uint4 kreg[K_ITERS], vreg[V_ITERS];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * KT;
+#pragma unroll
+        for (int i = 0; i < K_ITERS; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / CH, c = idx % CH;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            if (idx < KT * CH && k0 + key < len) kreg[i] = *(const uint4 *)(Kp + (size_t)(k0 + key) * ld + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < V_ITERS; ++i) {
+            const int c = wave + i * 4;
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (c < CH && k0 + lane < len) vreg[i] = *(const uint4 *)(Vp + (size_t)(k0 + lane) * ld + c * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *kb = smem + buf * (K_BYTES + V_BYTES);
+        char *vb = kb + K_BYTES;
+#pragma unroll
+        for (int i = 0; i < K_ITERS; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int key = idx / CH, c = idx % CH;
+            if (idx < KT * CH) {
+                const int cs = DH == 64 ? (c ^ ((key >> 1) & 7)) : (c ^ ((key >> 2) & 3));
+                *(uint4 *)(kb + key * KROW + cs * 16) = kreg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V_ITERS; ++i) {
+            const int c = wave + i * 4;
+            if (c < CH) {
+                const unsigned w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned short bits = (unsigned short)(w[e >> 1] >> ((e & 1) * 16));
+                    *(unsigned short *)(vb + (c * 8 + e) * VROW + lane * 2) = bits;
+                }
+            }
+        }
+    };
+
+    f32x16_t o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[d][j] = 0.f;
+    float m_run = NEG_INF_F, l_run = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_tiles) load_tile(kt + 1);
+        const char *kb = smem + buf * (K_BYTES + V_BYTES);
+        const char *vb = kb + K_BYTES;
+
+        // S^T[key][query] for the two 32-key blocks
+        f32x16_t s[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s[b][j] = 0.f;
+            const int key = b * 32 + r32;
+#pragma unroll
+            for (int ks = 0; ks < NQK; ++ks) {
+                const int c = 2 * ks + hh;
+                const int cs = DH == 64 ? (c ^ ((key >> 1) & 7)) : (c ^ ((key >> 2) & 3));
+                const half8_t kf = *(const half8_t *)(kb + key * KROW + cs * 16);
+                s[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[b], 0, 0, 0);
+            }
+        }
+        // scale, mask, running max
+        const int k0 = kt * KT;
+        float m_tile = NEG_INF_F;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int key = k0 + b * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                const bool ok = key < len && (!causal || key <= qi);
+                const float v = ok ? s[b][j] * scale : NEG_INF_F;
+                s[b][j] = v;
+                m_tile = fmaxf(m_tile, v);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float m_use = m_new == NEG_INF_F ? 0.f : m_new;  // fully masked row (padding query)
+        const float alpha = __expf(m_run - m_use);
+        float psum = 0.f;
+        half8_t pf[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float pv = __expf(s[b][j] - m_use);
+                psum += pv;
+                pf[b][j >> 3][j & 7] = (_Float16)pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[d][j] *= alpha;
+        // O^T[d][query] += V^T . P^T   (P straight from the accumulator registers; element j of
+        // k-step st of key block b is key b*32 + 16*st + 8*(j>>2) + 4*hh + (j&3))
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const char *vrow = vb + (d * 32 + r32) * VROW;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int kk = b * 32 + st * 16 + 4 * hh;
+                    const half4_t lo = *(const half4_t *)(vrow + kk * 2);
+                    const half4_t hi = *(const half4_t *)(vrow + (kk + 8) * 2);
+                    half8_t vf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        vf[i] = lo[i];
+                        vf[4 + i] = hi[i];
+                    }
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b][st], o[d], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < len) {
+        _Float16 *dst = ctx + (size_t)(seq0 + qi) * H + head * DH;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (_Float16)(o[d][4 * g + i] * inv);
+                *(half4_t *)(dst + d * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooling + (optional LayerNorm + projection handled by caller) + L2 normalisation
+// pool: 0 = mean over the sequence's tokens, 1 = first token (CLS), 2 = token index sel[b]
+// out fp32 [B, H]; x / max(||x||, 1e-12)
+// ---------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void pool_norm_kernel(const _Float16 *__restrict__ x,
+                                                         const int *__restrict__ cu_seqlens,
+                                                         const int *__restrict__ sel, OutT *__restrict__ out,
+                                                         int H, int pool, int normalize) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int s0 = cu_seqlens[b], s1 = cu_seqlens[b + 1];
+    float vals[4];  // H <= 1024
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        float v = 0.f;
+        if (c < H) {
+            if (pool == 0) {
+                for (int t = s0; t < s1; ++t) v += (float)x[(size_t)t * H + c];
+                const float cnt = (float)(s1 - s0);
+                v = v / fmaxf(cnt, 1e-9f);
+            } else {
+                const int t = pool == 1 ? s0 : s0 + sel[b];
+                v = (float)x[(size_t)t * H + c];
+            }
+        }
+        vals[i] = v;
+        sq += v * v;
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float inv = normalize ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < H) out[(size_t)b * H + c] = (OutT)(vals[i] * inv);
+    }
+}
+
+// out[b, :] = x[b, :] / max(||x[b, :]||, 1e-12)  (fp16 in, fp32 out), one wave per row
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const _Float16 *__restrict__ x, float *__restrict__ out,
+                                                              int B, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float sq = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = (float)x[(size_t)row * D + c];
+        sq += v * v;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
+    for (int c = lane; c < D; c += 64) out[(size_t)row * D + c] = (float)x[(size_t)row * D + c] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int launch_linear(const void *x, int M, int K, const void *wt, int N, const float *bias, int act,
+                  const void *resid, void *out, hipStream_t s) {
+    LinearParams p;
+    p.x = (const char *)x;
+    p.wt = (const char *)wt;
+    p.bias = bias;
+    p.resid = (const _Float16 *)resid;
+    p.out = (_Float16 *)out;
+    p.M = M, p.N = N, p.K = K, p.act = act;
+    const int cus = num_cus();
+    const long long big_tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    if (big_tiles >= cus && N % 256 == 0) {
+        linear_kernel<256, 256, 2, 4, 2><<<(unsigned)big_tiles, 512, 0, s>>>(p);
+    } else {
+        const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+        linear_kernel<128, 128, 2, 2, 3><<<(unsigned)tiles, 256, 0, s>>>(p);
+    }
+    return MMRAG_OK;
+}
+
+}  // namespace mmrag_impl
+using namespace mmrag_impl;
+
+extern "C" {
+
+int mmrag_linear_f16(const void *x, int64_t M, int K, const void *wt, int N, const float *bias, int act,
+                     const void *resid, void *out, void *stream) {
+    MMRAG_CHECK_ARG(x && wt && out, "linear: null pointer");
+    MMRAG_CHECK_ARG(M > 0 && M < INT_MAX && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    MMRAG_CHECK_ARG(K % 64 == 0, "linear: K=%d must be a multiple of 64 (128-byte fp16 slabs)", K);
+    MMRAG_CHECK_ARG(N % 4 == 0, "linear: N=%d must be a multiple of 4", N);
+    MMRAG_CHECK_ARG(act >= 0 && act <= 2, "linear: bad activation %d", act);
+    MMRAG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
+                        ((uintptr_t)resid % 8) == 0 && ((uintptr_t)bias % 16) == 0,
+                    "linear: misaligned pointer");
+    launch_linear(x, (int)M, K, wt, N, bias, act, resid, out, (hipStream_t)stream);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_layernorm_f16(const void *x, void *out, const float *gamma, const float *beta, int64_t T, int H,
+                        float eps, void *stream) {
+    MMRAG_CHECK_ARG(x && out && gamma && beta, "layernorm: null pointer");
+    MMRAG_CHECK_ARG(T > 0 && H > 0 && H % 2 == 0 && H <= 1024, "layernorm: bad shape T=%lld H=%d", (long long)T, H);
+    layernorm_kernel<<<(unsigned)((T + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        (const _Float16 *)x, (_Float16 *)out, gamma, beta, (int)T, H, eps);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_embed_ln_f16(const int32_t *ids, const int32_t *pos_ids, const void *tok, const void *pos,
+                       const void *type0, const float *gamma, const float *beta, void *out, int64_t T, int H,
+                       int vocab, int max_pos, float eps, void *stream) {
+    MMRAG_CHECK_ARG(ids && pos_ids && tok && pos && out, "embed_ln: null pointer");
+    MMRAG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "embed_ln: gamma/beta must both be given or both null");
+    MMRAG_CHECK_ARG(T > 0 && H > 0 && H % 2 == 0 && H <= 1024, "embed_ln: bad shape T=%lld H=%d", (long long)T, H);
+    embed_ln_kernel<<<(unsigned)((T + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        ids, pos_ids, (const _Float16 *)tok, (const _Float16 *)pos, (const _Float16 *)type0, gamma, beta,
+        (_Float16 *)out, (int)T, H, vocab, max_pos, eps);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_attention_f16(const void *qkv, const int32_t *cu_seqlens, void *ctx, int B, int max_len, int H,
+                        int n_heads, int causal, void *stream) {
+    MMRAG_CHECK_ARG(qkv && cu_seqlens && ctx, "attention: null pointer");
+    MMRAG_CHECK_ARG(B > 0 && max_len > 0 && n_heads > 0 && H % n_heads == 0, "attention: bad shape");
+    const int dh = H / n_heads;
+    MMRAG_CHECK_ARG(dh == 32 || dh == 64, "attention: head dim %d unsupported (32 or 64)", dh);
+    MMRAG_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 8) == 0, "attention: misaligned pointer");
+    const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)n_heads, (unsigned)B);
+    const float scale = 1.0f / sqrtf((float)dh);
+    if (dh == 64)
+        attention_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens, (_Float16 *)ctx,
+                                                                    H, scale, causal);
+    else
+        attention_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens, (_Float16 *)ctx,
+                                                                    H, scale, causal);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_pool_normalize_f16(const void *x, const int32_t *cu_seqlens, const int32_t *sel, float *out, int B,
+                             int H, int pool, int normalize, void *stream) {
+    MMRAG_CHECK_ARG(x && cu_seqlens && out, "pool: null pointer");
+    MMRAG_CHECK_ARG(B > 0 && H > 0 && H <= 1024, "pool: bad shape B=%d H=%d", B, H);
+    MMRAG_CHECK_ARG(pool >= 0 && pool <= 2 && (pool != 2 || sel), "pool: bad mode %d", pool);
+    pool_norm_kernel<float><<<(unsigned)B, 256, 0, (hipStream_t)stream>>>((const _Float16 *)x, cu_seqlens, sel, out, H,
+                                                                         pool, normalize);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// composite forward: all launches of one encoder pass, stream-ordered, no host sync
+// ---------------------------------------------------------------------------------------------
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+size_t mmrag_encoder_workspace_bytes(const mmrag_encoder_desc *d, int64_t T, int B) {
+    if (!d || T <= 0 || B <= 0) return 0;
+    const size_t H = (size_t)d->hidden, I = (size_t)d->intermediate;
+    size_t bytes = 0;
+    bytes += 2 * align256((size_t)T * H * 2);      // x, y
+    bytes += align256((size_t)T * 3 * H * 2);      // qkv
+    bytes += align256((size_t)T * H * 2);          // ctx
+    bytes += align256((size_t)T * I * 2);          // mlp hidden
+    bytes += 2 * align256((size_t)B * (H > (size_t)d->out_dim ? H : (size_t)d->out_dim) * 2);  // pooled, projected
+    return bytes + 256;
+}
+
+int mmrag_encoder_forward(const mmrag_encoder_desc *d, const void *const *w, const int32_t *ids,
+                          const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel, int64_t T, int B,
+                          int max_len, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    MMRAG_CHECK_ARG(d && w && ids && pos_ids && cu_seqlens && out, "encoder_forward: null pointer");
+    MMRAG_CHECK_ARG(d->arch == MMRAG_ARCH_BERT || d->arch == MMRAG_ARCH_PRELN, "encoder_forward: bad arch %d", d->arch);
+    MMRAG_CHECK_ARG(T > 0 && T < INT_MAX && B > 0 && max_len > 0, "encoder_forward: bad shape T=%lld B=%d", (long long)T, B);
+    MMRAG_CHECK_ARG(d->hidden % 64 == 0 && d->intermediate % 64 == 0 && d->hidden <= 1024,
+                    "encoder_forward: hidden/intermediate must be multiples of 64 (hidden <= 1024)");
+    MMRAG_CHECK_ARG(d->pool >= 0 && d->pool <= 2 && (d->pool != 2 || sel), "encoder_forward: bad pool mode");
+    const size_t need = mmrag_encoder_workspace_bytes(d, T, B);
+    if (!workspace || workspace_bytes < need) {
+        set_error("encoder_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MMRAG_EWORKSPACE;
+    }
+    const int H = d->hidden, I = d->intermediate, L = d->n_layers;
+    const size_t Tz = (size_t)T;
+    char *p = (char *)(((uintptr_t)workspace + 255) / 256 * 256);
+    auto take = [&](size_t bytes) { char *r = p; p += align256(bytes); return (void *)r; };
+    void *x = take(Tz * H * 2), *y = take(Tz * H * 2), *qkv = take(Tz * 3 * H * 2), *ctx = take(Tz * H * 2);
+    void *hm = take(Tz * I * 2);
+    const size_t pd = (size_t)(H > d->out_dim ? H : d->out_dim);
+    void *pooled = take((size_t)B * pd * 2), *proj = take((size_t)B * pd * 2);
+
+    int st;
+#define RUN(call) do { if ((st = (call)) != MMRAG_OK) return st; } while (0)
+    // embeddings
+    RUN(mmrag_embed_ln_f16(ids, pos_ids, w[0], w[1], w[2], (const float *)w[3], (const float *)w[4], x, T, H,
+                           d->vocab, d->max_pos, d->ln_eps, stream));
+    const void *const *lw = w + 5;
+    const int causal = d->causal;
+    for (int l = 0; l < L; ++l, lw += 12) {
+        const float *bqkv = (const float *)lw[1], *bo = (const float *)lw[3];
+        const float *g1 = (const float *)lw[4], *b1n = (const float *)lw[5];
+        const float *bi = (const float *)lw[7], *b2 = (const float *)lw[9];
+        const float *g2 = (const float *)lw[10], *b2n = (const float *)lw[11];
+        if (d->arch == MMRAG_ARCH_BERT) {
+            RUN(mmrag_linear_f16(x, T, H, lw[0], 3 * H, bqkv, MMRAG_ACT_NONE, nullptr, qkv, stream));
+            RUN(mmrag_attention_f16(qkv, cu_seqlens, ctx, B, max_len, H, d->n_heads, causal, stream));
+            RUN(mmrag_linear_f16(ctx, T, H, lw[2], H, bo, MMRAG_ACT_NONE, x, y, stream));
+            RUN(mmrag_layernorm_f16(y, x, g1, b1n, T, H, d->ln_eps, stream));
+            RUN(mmrag_linear_f16(x, T, H, lw[6], I, bi, d->act, nullptr, hm, stream));
+            RUN(mmrag_linear_f16(hm, T, I, lw[8], H, b2, MMRAG_ACT_NONE, x, y, stream));
+            RUN(mmrag_layernorm_f16(y, x, g2, b2n, T, H, d->ln_eps, stream));
+        } else {
+            RUN(mmrag_layernorm_f16(x, y, g1, b1n, T, H, d->ln_eps, stream));
+            RUN(mmrag_linear_f16(y, T, H, lw[0], 3 * H, bqkv, MMRAG_ACT_NONE, nullptr, qkv, stream));
+            RUN(mmrag_attention_f16(qkv, cu_seqlens, ctx, B, max_len, H, d->n_heads, causal, stream));
+            RUN(mmrag_linear_f16(ctx, T, H, lw[2], H, bo, MMRAG_ACT_NONE, x, x, stream));
+            RUN(mmrag_layernorm_f16(x, y, g2, b2n, T, H, d->ln_eps, stream));
+            RUN(mmrag_linear_f16(y, T, H, lw[6], I, bi, d->act, nullptr, hm, stream));
+            RUN(mmrag_linear_f16(hm, T, I, lw[8], H, b2, MMRAG_ACT_NONE, x, x, stream));
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (d->arch == MMRAG_ARCH_BERT) {
+        RUN(mmrag_pool_normalize_f16(x, cu_seqlens, sel, out, B, H, d->pool, d->normalize, stream));
+    } else {
+        // final LayerNorm (tail[0..1]), pooled token, bias-free projection (tail[2]), L2 normalise
+        RUN(mmrag_layernorm_f16(x, y, (const float *)lw[0], (const float *)lw[1], T, H, d->ln_eps, stream));
+        pool_norm_kernel<_Float16><<<(unsigned)B, 256, 0, s>>>((const _Float16 *)y, cu_seqlens, sel, (_Float16 *)pooled, H,
+                                                               d->pool, 0);
+        MMRAG_CHECK_HIP(hipGetLastError());
+        RUN(mmrag_linear_f16(pooled, B, H, lw[2], d->out_dim, nullptr, MMRAG_ACT_NONE, nullptr, proj, stream));
+        normalize_rows_kernel<<<(unsigned)((B + 3) / 4), 256, 0, s>>>((const _Float16 *)proj, out, B, d->out_dim);
+        MMRAG_CHECK_HIP(hipGetLastError());
+    }
+#undef RUN
+    return MMRAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""Host side of the text encoder: what `SentenceTransformer(name, device)` is to the reference
+(app/utils/embedder.py:245-248) and `.encode(...)` at :397-403.
+
+The forward pass itself is mmrag_encoder_forward() in libmmrag.so (hand-written HIP kernels);
+this module only owns the weight table in HBM, packs token ids, and hands pointers over.
+There is no eager / CPU forward here.
+
+Weights: the reference loads a checkpoint by hub NAME, which needs a network.  Here a model is
+either loaded from a user-supplied LOCAL directory in Hugging Face layout (config.json +
+model.safetensors [+ vocab.txt]) or random-initialised with the named architecture (what the
+benchmarks use; no checkpoint can be fetched in this environment).
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    name: str
+    n_layers: int
+    hidden: int
+    n_heads: int
+    intermediate: int
+    vocab: int = 30522
+    max_pos: int = 512
+    max_seq_length: int = 256       # sentence-transformers truncation length
+    pool: str = "mean"              # "mean" | "cls"
+    ln_eps: float = 1e-12
+    arch: str = "bert"
+
+    @property
+    def dim(self) -> int:
+        return self.hidden
+
+
+# config.py:102-105 SENTENCE_TRANSFORMER_MODEL default, plus the BASELINE.json config-3 model
+PRESETS: Dict[str, EncoderConfig] = {
+    "all-MiniLM-L6-v2": EncoderConfig("all-MiniLM-L6-v2", 6, 384, 12, 1536, max_seq_length=256, pool="mean"),
+    "sentence-transformers/all-MiniLM-L6-v2": EncoderConfig("all-MiniLM-L6-v2", 6, 384, 12, 1536,
+                                                            max_seq_length=256, pool="mean"),
+    "BAAI/bge-base-en-v1.5": EncoderConfig("bge-base-en-v1.5", 12, 768, 12, 3072, max_seq_length=512, pool="cls"),
+    "bge-base-en-v1.5": EncoderConfig("bge-base-en-v1.5", 12, 768, 12, 3072, max_seq_length=512, pool="cls"),
+}
+
+
+def _layer_names(l: int):
+    p = f"encoder.layer.{l}."
+    return p
+
+
+class DeviceEncoder:
+    """BERT-family sentence encoder resident on one GPU."""
+
+    def __init__(self, cfg: EncoderConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device="cuda:0"):
+        _native.lib()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._tensors: List[torch.Tensor] = []   # keeps the HBM weight table alive
+        ptrs: List[Optional[int]] = []
+
+        def up(x, dtype):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+            self._tensors.append(t)
+            ptrs.append(t.data_ptr())
+
+        g = lambda k: weights[k]  # noqa: E731
+        up(g("embeddings.word_embeddings.weight"), torch.float16)
+        up(g("embeddings.position_embeddings.weight"), torch.float16)
+        tt = g("embeddings.token_type_embeddings.weight")
+        up(tt[0], torch.float16)
+        up(g("embeddings.LayerNorm.weight"), torch.float32)
+        up(g("embeddings.LayerNorm.bias"), torch.float32)
+        cat = (lambda xs: torch.cat([x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x)) for x in xs], 0))
+        for l in range(cfg.n_layers):
+            p = f"encoder.layer.{l}."
+            up(cat([g(p + f"attention.self.{n}.weight") for n in ("query", "key", "value")]), torch.float16)
+            up(cat([g(p + f"attention.self.{n}.bias") for n in ("query", "key", "value")]), torch.float32)
+            up(g(p + "attention.output.dense.weight"), torch.float16)
+            up(g(p + "attention.output.dense.bias"), torch.float32)
+            up(g(p + "attention.output.LayerNorm.weight"), torch.float32)
+            up(g(p + "attention.output.LayerNorm.bias"), torch.float32)
+            up(g(p + "intermediate.dense.weight"), torch.float16)
+            up(g(p + "intermediate.dense.bias"), torch.float32)
+            up(g(p + "output.dense.weight"), torch.float16)
+            up(g(p + "output.dense.bias"), torch.float32)
+            up(g(p + "output.LayerNorm.weight"), torch.float32)
+            up(g(p + "output.LayerNorm.bias"), torch.float32)
+        self._ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        self.desc = _native.EncoderDesc(
+            arch=_native.ARCH_BERT, n_layers=cfg.n_layers, hidden=cfg.hidden, n_heads=cfg.n_heads,
+            intermediate=cfg.intermediate, vocab=cfg.vocab, max_pos=cfg.max_pos,
+            pool=_native.POOL_MEAN if cfg.pool == "mean" else _native.POOL_FIRST, act=_native.ACT_GELU, causal=0,
+            normalize=1, out_dim=cfg.hidden, ln_eps=cfg.ln_eps)
+        self._workspace: Optional[torch.Tensor] = None
+
+    # ---------------------------------------------------------------- constructors ---------
+    @classmethod
+    def random_init(cls, cfg: EncoderConfig, seed: int = 0, device="cuda:0", std: float = 0.02) -> "DeviceEncoder":
+        """Seeded random weights of the named architecture, generated on the device."""
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        H, I = cfg.hidden, cfg.intermediate
+
+        def mat(o, i):
+            return torch.randn((o, i), generator=g, device=dev) * std
+
+        def vec(n, base=0.0, scale=0.02):
+            return base + torch.randn((n,), generator=g, device=dev) * scale
+
+        w = {"embeddings.word_embeddings.weight": mat(cfg.vocab, H),
+             "embeddings.position_embeddings.weight": mat(cfg.max_pos, H),
+             "embeddings.token_type_embeddings.weight": mat(2, H),
+             "embeddings.LayerNorm.weight": vec(H, 1.0), "embeddings.LayerNorm.bias": vec(H)}
+        for l in range(cfg.n_layers):
+            p = f"encoder.layer.{l}."
+            for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+                w[p + n + ".weight"] = mat(H, H)
+                w[p + n + ".bias"] = vec(H)
+            w[p + "attention.output.LayerNorm.weight"] = vec(H, 1.0)
+            w[p + "attention.output.LayerNorm.bias"] = vec(H)
+            w[p + "intermediate.dense.weight"] = mat(I, H)
+            w[p + "intermediate.dense.bias"] = vec(I)
+            w[p + "output.dense.weight"] = mat(H, I)
+            w[p + "output.dense.bias"] = vec(H)
+            w[p + "output.LayerNorm.weight"] = vec(H, 1.0)
+            w[p + "output.LayerNorm.bias"] = vec(H)
+        return cls(cfg, w, device)
+
+    @classmethod
+    def from_local_dir(cls, path: str, device="cuda:0", max_seq_length: Optional[int] = None) -> "DeviceEncoder":
+        """Load a BERT-family checkpoint from a local Hugging Face style directory
+        (config.json + model.safetensors).  Nothing is downloaded."""
+        from safetensors.numpy import load_file
+
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        pool = "mean"
+        pool_cfg = os.path.join(path, "1_Pooling", "config.json")
+        if os.path.exists(pool_cfg):
+            with open(pool_cfg) as f:
+                if json.load(f).get("pooling_mode_cls_token"):
+                    pool = "cls"
+        st_cfg = os.path.join(path, "sentence_bert_config.json")
+        if max_seq_length is None and os.path.exists(st_cfg):
+            with open(st_cfg) as f:
+                max_seq_length = json.load(f).get("max_seq_length")
+        cfg = EncoderConfig(os.path.basename(os.path.normpath(path)), c["num_hidden_layers"], c["hidden_size"],
+                            c["num_attention_heads"], c["intermediate_size"], c["vocab_size"],
+                            c["max_position_embeddings"], max_seq_length or c["max_position_embeddings"], pool,
+                            c.get("layer_norm_eps", 1e-12))
+        raw = load_file(os.path.join(path, "model.safetensors"))
+        w = {(k[5:] if k.startswith("bert.") else k): v for k, v in raw.items()}
+        return cls(cfg, w, device)
+
+    # ---------------------------------------------------------------- forward ---------------
+    def pack(self, sequences: Sequence[Sequence[int]]):
+        """Truncate to max_seq_length and pack: (ids [T], pos_ids [T], cu_seqlens [B+1], max_len)."""
+        L = min(self.cfg.max_seq_length, self.cfg.max_pos)
+        seqs = [np.asarray(s[:L], dtype=np.int32) for s in sequences]
+        if any(len(s) == 0 for s in seqs):
+            raise ValueError("empty token sequence")
+        lens = np.array([len(s) for s in seqs], dtype=np.int32)
+        cu = np.zeros(len(seqs) + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        ids = np.concatenate(seqs)
+        pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
+        return ids, pos, cu, int(lens.max())
+
+    def encode_ids(self, sequences: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Token-id sequences -> L2-normalised embeddings [B, dim] float32 on the device."""
+        ids, pos, cu, max_len = self.pack(sequences)
+        d = self.device
+        ids_t = torch.from_numpy(ids).to(d, non_blocking=True)
+        pos_t = torch.from_numpy(pos).to(d, non_blocking=True)
+        cu_t = torch.from_numpy(cu).to(d, non_blocking=True)
+        return self.forward_packed(ids_t, pos_t, cu_t, max_len)
+
+    def forward_packed(self, ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        T, B = ids.numel(), cu_seqlens.numel() - 1
+        need = _native.encoder_workspace_bytes(self.desc, T, B)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return _native.encoder_forward(self.desc, self._ptrs, ids, pos_ids, cu_seqlens, max_len,
+                                       workspace=self._workspace, out=out)
+
+    @property
+    def dim(self) -> int:
+        return self.cfg.hidden
+
+    def flops_per_sequence(self, s: int) -> float:
+        """L * S * (24 H^2 + 4 S H)"""
+        H = self.cfg.hidden
+        return float(self.cfg.n_layers) * s * (24.0 * H * H + 4.0 * s * H)
