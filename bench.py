@@ -242,7 +242,8 @@ def main():
         try:
             from multimodal_rag_amd import bench_embed
 
-            emb = bench_embed.run(dev, rank, world, steps=max(3, args.steps // 5), warmup=2)
+            emb = bench_embed.run(dev, rank, world, steps=max(3, args.steps // 5), warmup=2,
+                                  with_cpu_baseline=not args.no_cpu_baseline)
             if rank == 0 and emb is not None:
                 result["embed"] = emb
         except ImportError:

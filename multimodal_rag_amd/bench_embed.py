@@ -1,0 +1,103 @@
+"""Embed leg of bench.py: chunks embedded / s (encoder forward + append into the corpus shard).
+
+Workload: bge-base-en-v1.5 architecture (BASELINE.json configs[2]; L=12, H=768, 12 heads,
+I=3072, CLS pooling), random-init fp16 weights, synthetic token ids ([CLS] body [SEP]),
+256 chunks x 256 tokens per step per GPU (CHUNK_SIZE=1000 characters ~ 250 word pieces).
+Data-parallel: every rank embeds its own chunks into its own shard, no collective.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import _native
+from .encoder import PRESETS, DeviceEncoder, random_bert_weights
+
+CHUNKS_PER_STEP = 256
+SEQ = 256
+MFMA_F16_PEAK_TFLOPS = 2500.0
+
+
+def synthetic_ids(n_chunks: int, seq: int, vocab: int, seed: int):
+    g = np.random.default_rng(seed)
+    ids = g.integers(1000, vocab, size=(n_chunks, seq), dtype=np.int64).astype(np.int32)
+    ids[:, 0] = 101
+    ids[:, -1] = 102
+    return ids
+
+
+def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_baseline: bool = True):
+    import torch.distributed as dist
+
+    cfg = PRESETS["BAAI/bge-base-en-v1.5"]
+    w = random_bert_weights(cfg, seed=4321, device=dev)
+    enc = DeviceEncoder(cfg, w, dev)
+    ids_np = synthetic_ids(CHUNKS_PER_STEP, SEQ, cfg.vocab, seed=100 + rank)
+    ids = torch.from_numpy(ids_np.reshape(-1)).to(dev)
+    pos = torch.arange(SEQ, dtype=torch.int32, device=dev).repeat(CHUNKS_PER_STEP)
+    cu = torch.arange(0, (CHUNKS_PER_STEP + 1) * SEQ, SEQ, dtype=torch.int32, device=dev)
+    out = torch.empty((CHUNKS_PER_STEP, cfg.dim), dtype=torch.float32, device=dev)
+    ld = _native.padded_dim(cfg.dim, torch.float16)
+    shard = torch.zeros((CHUNKS_PER_STEP * (steps + warmup), ld), dtype=torch.float16, device=dev)
+
+    def step(i):
+        enc.forward_packed(ids, pos, cu, SEQ, out=out)
+        _native.append_rows(shard, i * CHUNKS_PER_STEP, out, cfg.dim)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        step(warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    dev_ms = e0.elapsed_time(e1) / steps
+    flops_step = CHUNKS_PER_STEP * enc.flops_per_sequence(SEQ)
+    tflops = flops_step / (dev_ms * 1e-3) / 1e12
+    res = {
+        "metric": "chunks embedded/sec", "value": round(world * CHUNKS_PER_STEP * steps / dt, 1), "unit": "chunks/s",
+        "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "scaling": "weak", "dtype": "f16",
+        "config": {"workload": f"embed: bge-base-en-v1.5 shape (L12 H768 I3072, CLS pool), random-init fp16, "
+                               f"{CHUNKS_PER_STEP} chunks x {SEQ} tokens per step per GPU, forward + append to shard",
+                   "chunks_per_step_per_gpu": CHUNKS_PER_STEP, "seq_len": SEQ, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "linear_kernel (+ attention_kernel)",
+                     "achieved": round(tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                     "flops_per_chunk": enc.flops_per_sequence(SEQ), "device_ms_per_step": round(dev_ms, 3)},
+    }
+    if with_cpu_baseline and world == 1:
+        from oracle import encoder_oracle as E
+
+        shape = E.BertShape(cfg.n_layers, cfg.hidden, cfg.n_heads, cfg.intermediate, cfg.vocab, cfg.max_pos,
+                            cfg.ln_eps, cfg.pool)
+        w16 = E.round_weights_fp16({k: v.float().cpu().numpy() for k, v in w.items()})
+        n_cpu = 4
+        seqs = [ids_np[i].tolist() for i in range(n_cpu)]
+        t0 = time.perf_counter()
+        ref = E.bert_encode(shape, w16, seqs)
+        cdt = time.perf_counter() - t0
+        got = out[:n_cpu].cpu().numpy()
+        res["cpu_baseline"] = {"value": round(n_cpu / cdt, 3), "unit": "chunks/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"oracle/encoder_oracle.py (numpy fp32) on {n_cpu} chunks x {SEQ} tokens"}
+        res["parity_vs_oracle"] = bool(np.abs(got - ref).max() <= 4e-3 and (got * ref).sum(1).min() >= 0.9999)
+        res["max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+    return res

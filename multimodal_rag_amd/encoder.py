@@ -53,9 +53,38 @@ PRESETS: Dict[str, EncoderConfig] = {
 }
 
 
-def _layer_names(l: int):
-    p = f"encoder.layer.{l}."
-    return p
+
+def random_bert_weights(cfg: EncoderConfig, seed: int = 0, device="cuda:0", std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Seeded random float32 weights (HF BertModel names) generated on `device`: what the
+    benchmarks and the checkpoint-less service mode use (no weights can be fetched here)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    H, I = cfg.hidden, cfg.intermediate
+
+    def mat(o, i):
+        return torch.randn((o, i), generator=g, device=dev) * std
+
+    def vec(n, base=0.0, scale=0.02):
+        return base + torch.randn((n,), generator=g, device=dev) * scale
+
+    w = {"embeddings.word_embeddings.weight": mat(cfg.vocab, H),
+         "embeddings.position_embeddings.weight": mat(cfg.max_pos, H),
+         "embeddings.token_type_embeddings.weight": mat(2, H),
+         "embeddings.LayerNorm.weight": vec(H, 1.0), "embeddings.LayerNorm.bias": vec(H)}
+    for l in range(cfg.n_layers):
+        p = f"encoder.layer.{l}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            w[p + n + ".weight"] = mat(H, H)
+            w[p + n + ".bias"] = vec(H)
+        w[p + "attention.output.LayerNorm.weight"] = vec(H, 1.0)
+        w[p + "attention.output.LayerNorm.bias"] = vec(H)
+        w[p + "intermediate.dense.weight"] = mat(I, H)
+        w[p + "intermediate.dense.bias"] = vec(I)
+        w[p + "output.dense.weight"] = mat(H, I)
+        w[p + "output.dense.bias"] = vec(H)
+        w[p + "output.LayerNorm.weight"] = vec(H, 1.0)
+        w[p + "output.LayerNorm.bias"] = vec(H)
+    return w
 
 
 class DeviceEncoder:
@@ -108,34 +137,7 @@ class DeviceEncoder:
     @classmethod
     def random_init(cls, cfg: EncoderConfig, seed: int = 0, device="cuda:0", std: float = 0.02) -> "DeviceEncoder":
         """Seeded random weights of the named architecture, generated on the device."""
-        dev = torch.device(device)
-        g = torch.Generator(device=dev).manual_seed(seed)
-        H, I = cfg.hidden, cfg.intermediate
-
-        def mat(o, i):
-            return torch.randn((o, i), generator=g, device=dev) * std
-
-        def vec(n, base=0.0, scale=0.02):
-            return base + torch.randn((n,), generator=g, device=dev) * scale
-
-        w = {"embeddings.word_embeddings.weight": mat(cfg.vocab, H),
-             "embeddings.position_embeddings.weight": mat(cfg.max_pos, H),
-             "embeddings.token_type_embeddings.weight": mat(2, H),
-             "embeddings.LayerNorm.weight": vec(H, 1.0), "embeddings.LayerNorm.bias": vec(H)}
-        for l in range(cfg.n_layers):
-            p = f"encoder.layer.{l}."
-            for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
-                w[p + n + ".weight"] = mat(H, H)
-                w[p + n + ".bias"] = vec(H)
-            w[p + "attention.output.LayerNorm.weight"] = vec(H, 1.0)
-            w[p + "attention.output.LayerNorm.bias"] = vec(H)
-            w[p + "intermediate.dense.weight"] = mat(I, H)
-            w[p + "intermediate.dense.bias"] = vec(I)
-            w[p + "output.dense.weight"] = mat(H, I)
-            w[p + "output.dense.bias"] = vec(H)
-            w[p + "output.LayerNorm.weight"] = vec(H, 1.0)
-            w[p + "output.LayerNorm.bias"] = vec(H)
-        return cls(cfg, w, device)
+        return cls(cfg, random_bert_weights(cfg, seed, device, std), device)
 
     @classmethod
     def from_local_dir(cls, path: str, device="cuda:0", max_seq_length: Optional[int] = None) -> "DeviceEncoder":
