@@ -1,0 +1,48 @@
+"""Settings for the hot path: the subset of the reference's `config.Settings`
+(config.py:18-132) that the embed/retrieve path reads, with the same key names, defaults and
+environment-variable overrides.  Extra keys (MMRAG_*) select the MI355X engine's options."""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+
+def _b(name: str, default: str) -> bool:
+    return os.getenv(name, default).lower() == "true"
+
+
+@dataclass
+class Settings:
+    # config.py:58-59
+    CHROMA_PERSIST_DIR: str = field(default_factory=lambda: os.getenv("CHROMA_PERSIST_DIR", "./chroma_db"))
+    CHROMA_COLLECTION_NAME: str = field(default_factory=lambda: os.getenv("CHROMA_COLLECTION_NAME", "multimodal_rag"))
+    # config.py:64-66
+    CHUNK_SIZE: int = field(default_factory=lambda: int(os.getenv("CHUNK_SIZE", "1000")))
+    CHUNK_OVERLAP: int = field(default_factory=lambda: int(os.getenv("CHUNK_OVERLAP", "200")))
+    TOP_K_RESULTS: int = field(default_factory=lambda: int(os.getenv("TOP_K_RESULTS", "5")))
+    # config.py:79-81 (api.py:92-95 does not read them; kept for parity)
+    EMBEDDER_BATCH_SIZE: int = field(default_factory=lambda: int(os.getenv("EMBEDDER_BATCH_SIZE", "32")))
+    EMBEDDER_CACHE_SIZE: int = field(default_factory=lambda: int(os.getenv("EMBEDDER_CACHE_SIZE", "1000")))
+    EMBEDDER_ENABLE_CACHE: bool = field(default_factory=lambda: _b("EMBEDDER_ENABLE_CACHE", "true"))
+    # config.py:86-89
+    RETRIEVER_ENABLE_COMPRESSION: bool = field(default_factory=lambda: _b("RETRIEVER_ENABLE_COMPRESSION", "true"))
+    RETRIEVER_ENABLE_CACHE: bool = field(default_factory=lambda: _b("RETRIEVER_ENABLE_CACHE", "true"))
+    RETRIEVER_CACHE_SIZE: int = field(default_factory=lambda: int(os.getenv("RETRIEVER_CACHE_SIZE", "100")))
+    # config.py:102-106
+    SENTENCE_TRANSFORMER_MODEL: str = field(
+        default_factory=lambda: os.getenv("SENTENCE_TRANSFORMER_MODEL", "all-MiniLM-L6-v2"))
+    CLIP_MODEL: str = field(default_factory=lambda: os.getenv("CLIP_MODEL", "ViT-B/32"))
+    # config.py:117-119
+    LOG_LEVEL: str = field(default_factory=lambda: os.getenv("LOG_LEVEL", "INFO"))
+    ENABLE_CORS: bool = field(default_factory=lambda: _b("ENABLE_CORS", "true"))
+    MAX_UPLOAD_SIZE: int = field(default_factory=lambda: int(os.getenv("MAX_UPLOAD_SIZE", "50")))  # MB
+
+    # ---- engine options (not in the reference) ----
+    # local Hugging Face style directory with config.json + model.safetensors + vocab.txt; when
+    # empty the named architecture is random-initialised and a stand-in tokenizer is used
+    MMRAG_MODEL_DIR: str = field(default_factory=lambda: os.getenv("MMRAG_MODEL_DIR", ""))
+    MMRAG_INDEX_DTYPE: str = field(default_factory=lambda: os.getenv("MMRAG_INDEX_DTYPE", "float16"))
+    MMRAG_WEIGHT_SEED: int = field(default_factory=lambda: int(os.getenv("MMRAG_WEIGHT_SEED", "0")))
+
+
+settings = Settings()

@@ -11,7 +11,7 @@ kernel's 128-byte slabs); ids / documents / metadata stay in host tables indexed
 SURVEY.md section 8b "Ownership" lays out.  Search is exact (fused MFMA GEMM + top-k in
 libmmrag.so), distance = 1 - cos (the committed collection's hnsw:space=cosine).
 
-No arithmetic happens in this file: torch provides device buffers and copies only.
+No vector arithmetic happens in this file: torch provides device buffers and copies only.
 """
 from __future__ import annotations
 
@@ -170,23 +170,51 @@ class VectorIndex:
             self._metadatas.extend(metadatas if metadatas is not None else [{} for _ in range(m)])
             self._n += m
 
-    def _alive_bits(self, where: Optional[Dict[str, Any]]) -> Optional[torch.Tensor]:
+    def _alive_words(self, where: Optional[Dict[str, Any]]) -> Optional[np.ndarray]:
         if not where:
             return None
         words = np.zeros((self._n + 31) // 32 + 8, dtype=np.uint32)
         idx = np.fromiter((i for i in range(self._n) if match_where(self._metadatas[i], where)), dtype=np.int64)
         if idx.size:
             np.bitwise_or.at(words, idx // 32, np.uint32(1) << (idx % 32).astype(np.uint32))
+        return words
+
+    def _to_bits(self, words: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(words.view(np.int32)).to(self.device)
 
     def search(self, query_embeddings, n_results: int, where: Optional[Dict[str, Any]] = None):
-        """Raw device search: (scores [B, k] float32 desc, rows [B, k] int64, -1 = none)."""
-        if n_results < 1 or n_results > _native.MAX_K:
-            raise ValueError(f"n_results must be in 1..{_native.MAX_K}")
+        """Raw device search: (scores [B, k] float32 desc, rows [B, k] int64, -1 = none).
+
+        The kernel selects up to MAX_K = 20 per pass (api.py:163 caps top_k at 20).  Deeper
+        requests (get_similar_documents asks for n_results + 1, embedder.py:903) run further
+        passes with the rows already returned masked out -- still exact, still ordered."""
+        if n_results < 1:
+            raise ValueError("n_results must be >= 1")
         with self._lock:
             q = self._pack_queries(query_embeddings)
-            bits = self._alive_bits(where)
-            return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
+            words = self._alive_words(where)
+            if n_results <= _native.MAX_K:
+                bits = self._to_bits(words) if words is not None else None
+                return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
+            if q.shape[0] != 1:
+                raise ValueError(f"n_results > {_native.MAX_K} is supported for single queries only")
+            if words is None:
+                words = np.zeros((self._n + 31) // 32 + 8, dtype=np.uint32)
+                idx = np.arange(self._n, dtype=np.int64)
+                np.bitwise_or.at(words, idx // 32, np.uint32(1) << (idx % 32).astype(np.uint32))
+            out_s, out_r, left = [], [], n_results
+            while left > 0:
+                k = min(left, _native.MAX_K)
+                s, r = _native.cosine_topk(q, self._matrix, self._n, self.dim, k, alive_bits=self._to_bits(words))
+                out_s.append(s)
+                out_r.append(r)
+                got = r[0].cpu().numpy()
+                got = got[got >= 0]
+                if got.size < k:
+                    break
+                np.bitwise_and.at(words, got // 32, ~(np.uint32(1) << (got % 32).astype(np.uint32)))
+                left -= k
+            return torch.cat(out_s, 1), torch.cat(out_r, 1)
 
     def query(self, query_embeddings, n_results: int = 10, where: Optional[Dict[str, Any]] = None,
               include: Sequence[str] = ("metadatas", "documents", "distances")) -> Dict[str, Any]:

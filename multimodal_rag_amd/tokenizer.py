@@ -1,0 +1,121 @@
+"""Host-side tokenisation for the encoder (the step before the hot path).
+
+`WordPieceTokenizer` restates BERT's uncased BasicTokenizer + WordPiece (what
+sentence-transformers runs for all-MiniLM-L6-v2 / bge) over a user-supplied LOCAL vocab.txt.
+`HashTokenizer` is a clearly-labelled STAND-IN for when no vocabulary is available (this
+environment has none and cannot fetch one): deterministic, same id range and special tokens,
+but not a trained vocabulary.
+"""
+from __future__ import annotations
+
+import hashlib
+import unicodedata
+from typing import Dict, List
+
+CLS, SEP, PAD, UNK = 101, 102, 0, 100
+
+
+def _is_punct(ch: str) -> bool:
+    cp = ord(ch)
+    if (33 <= cp <= 47) or (58 <= cp <= 64) or (91 <= cp <= 96) or (123 <= cp <= 126):
+        return True
+    return unicodedata.category(ch).startswith("P")
+
+
+def _is_cjk(cp: int) -> bool:
+    return ((0x4E00 <= cp <= 0x9FFF) or (0x3400 <= cp <= 0x4DBF) or (0x20000 <= cp <= 0x2A6DF)
+            or (0x2A700 <= cp <= 0x2B73F) or (0x2B740 <= cp <= 0x2B81F) or (0x2B820 <= cp <= 0x2CEAF)
+            or (0xF900 <= cp <= 0xFAFF) or (0x2F800 <= cp <= 0x2FA1F))
+
+
+def basic_tokenize(text: str, lower: bool = True) -> List[str]:
+    """BERT BasicTokenizer: clean, space CJK, whitespace split, lower + strip accents, split punctuation."""
+    out = []
+    for ch in text:
+        cp = ord(ch)
+        if cp == 0 or cp == 0xFFFD or (unicodedata.category(ch) in ("Cc", "Cf") and ch not in "\t\n\r"):
+            continue
+        if _is_cjk(cp):
+            out.append(f" {ch} ")
+        elif ch in " \t\n\r" or unicodedata.category(ch) == "Zs":
+            out.append(" ")
+        else:
+            out.append(ch)
+    words = "".join(out).split()
+    tokens: List[str] = []
+    for w in words:
+        if lower:
+            w = w.lower()
+            w = "".join(c for c in unicodedata.normalize("NFD", w) if unicodedata.category(c) != "Mn")
+        cur = ""
+        for ch in w:
+            if _is_punct(ch):
+                if cur:
+                    tokens.append(cur)
+                    cur = ""
+                tokens.append(ch)
+            else:
+                cur += ch
+        if cur:
+            tokens.append(cur)
+    return tokens
+
+
+class WordPieceTokenizer:
+    def __init__(self, vocab: Dict[str, int], lower: bool = True, max_chars_per_word: int = 100):
+        self.vocab = vocab
+        self.lower = lower
+        self.max_chars = max_chars_per_word
+        self.cls = vocab.get("[CLS]", CLS)
+        self.sep = vocab.get("[SEP]", SEP)
+        self.unk = vocab.get("[UNK]", UNK)
+        self.vocab_size = max(vocab.values()) + 1
+
+    @classmethod
+    def from_vocab_file(cls, path: str, lower: bool = True) -> "WordPieceTokenizer":
+        with open(path, encoding="utf-8") as f:
+            vocab = {line.rstrip("\n"): i for i, line in enumerate(f)}
+        return cls(vocab, lower)
+
+    def _wordpiece(self, word: str) -> List[int]:
+        if len(word) > self.max_chars:
+            return [self.unk]
+        ids, start = [], 0
+        while start < len(word):
+            end, cur = len(word), None
+            while start < end:
+                piece = word[start:end] if start == 0 else "##" + word[start:end]
+                if piece in self.vocab:
+                    cur = self.vocab[piece]
+                    break
+                end -= 1
+            if cur is None:
+                return [self.unk]
+            ids.append(cur)
+            start = end
+        return ids
+
+    def encode(self, text: str, max_length: int) -> List[int]:
+        ids = [self.cls]
+        for w in basic_tokenize(text, self.lower):
+            ids.extend(self._wordpiece(w))
+            if len(ids) >= max_length - 1:
+                break
+        return ids[: max_length - 1] + [self.sep]
+
+
+class HashTokenizer:
+    """STAND-IN tokenizer (no trained vocabulary available offline): BERT basic tokenisation, then
+    each word maps to id 1000 + md5(word) mod (vocab - 1000).  [CLS]=101, [SEP]=102."""
+
+    def __init__(self, vocab_size: int = 30522, lower: bool = True):
+        self.vocab_size = vocab_size
+        self.lower = lower
+        self.cls, self.sep = CLS, SEP
+
+    def encode(self, text: str, max_length: int) -> List[int]:
+        ids = [self.cls]
+        span = self.vocab_size - 1000
+        for w in basic_tokenize(text, self.lower)[: max_length - 2]:
+            ids.append(1000 + int.from_bytes(hashlib.md5(w.encode("utf-8")).digest()[:8], "little") % span)
+        return ids + [self.sep]

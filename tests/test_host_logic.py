@@ -1,0 +1,214 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no kernels): cache and
+ordering semantics, retry/error conventions, key mapping, chunker, payload format."""
+import asyncio
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from multimodal_rag_amd import ingest
+from multimodal_rag_amd.embedder import EmbeddingManager, LRUCache
+from multimodal_rag_amd.retriever import DocumentCache, InProcessKV, MultiVectorRetriever
+from oracle import host_oracle as H
+from tests.fakes import FakeEngine
+
+
+def run(coro):
+    return asyncio.run(coro)
+
+
+async def no_sleep(_):
+    return None
+
+
+def manager(**kw):
+    eng = FakeEngine()
+    m = EmbeddingManager(engine=eng, **kw)
+    m._sleep = no_sleep
+    return m, eng
+
+
+def summaries(n, kinds=("text",)):
+    return [{"id": f"{kinds[i % len(kinds)]}_{i}", "summary": f"summary number {i}", "raw": f"raw {i}",
+             "type": kinds[i % len(kinds)]} for i in range(n)]
+
+
+# ---------------------------------------------------------------- LRU cache (embedder.py:26-80)
+def test_lru_cache_semantics():
+    c = LRUCache(maxsize=2)
+    assert c.get("a") is None and c.misses == 1
+    c.put("a", [1.0]); c.put("b", [2.0])
+    assert c.get("a") == [1.0]           # refreshes a
+    c.put("c", [3.0])                    # evicts b (least recently used)
+    assert c.get("b") is None and c.get("c") == [3.0]
+    assert c.get_stats() == {"size": 2, "maxsize": 2, "hits": 2, "misses": 2, "hit_rate": 0.5}
+    c.clear()
+    assert c.get_stats()["hits"] == 0 and c.get_stats()["hit_rate"] == 0.0
+    assert DocumentCache(1).get_stats()["hit_rate"] == 0.0
+
+
+# ---------------------------------------------------------------- embed_texts_batch (:266-347)
+def test_embed_batch_order_cache_and_slicing():
+    m, eng = manager(batch_size=4)
+    texts = [f"t{i}" for i in range(10)]
+    a = run(m.embed_texts_batch(texts))
+    assert eng.calls == [4, 4, 2]                       # sequential slices of batch_size (:359-373)
+    assert len(a) == 10 and all(isinstance(x, list) and isinstance(x[0], float) for x in a)
+    b = run(m.embed_texts_batch(["new"] + texts[::-1]))  # 10 hits, 1 miss, order restored (:330-332)
+    assert eng.calls[-1] == 1
+    assert b[1:] == a[::-1]
+    assert m.stats["total_embeddings_created"] == 11
+    assert m.stats["cache_hits"] == 10 and m.stats["cache_misses"] == 11
+    assert run(m.embed_texts_batch([])) == []
+    assert m._get_cache_key("x") == H.cache_key("x")
+
+
+def test_embed_batch_without_cache():
+    m, eng = manager(enable_cache=False)
+    run(m.embed_texts_batch(["a", "a"]))
+    assert eng.calls == [2] and run(m.get_cache_stats()) == {"enabled": False}
+
+
+# ---------------------------------------------------------------- embed_and_store (:428-500)
+def test_embed_and_store_counts_ids_metadata():
+    m, eng = manager()
+    s = summaries(7, ("text", "table", "image")) + [{"id": "x_9", "summary": "odd", "raw": "", "type": "audio"}]
+    counts = run(m.embed_and_store(s, "doc_abc123def456"))
+    assert counts == {"text": 3, "table": 2, "image": 2}            # unknown types uncounted (:477-479)
+    col = eng.collections[0]
+    assert col.ids[0] == "doc_abc123def456_text_0" == H.chroma_id("doc_abc123def456", "text_0")
+    assert col.metas[1] == {"doc_id": "doc_abc123def456", "item_id": "table_1", "type": "table"}
+    assert col.docs[2] == "summary number 2"
+    assert m.stats["total_items_stored"] == 8
+    assert run(m.embed_and_store([], "doc_x")) == {"text": 0, "table": 0, "image": 0}   # (:448-450)
+
+
+def test_store_retry_then_success_and_exhaustion():
+    m, eng = manager()
+    run(m.initialize())
+    eng.collections[0].fail_next = 2
+    assert run(m.embed_and_store(summaries(2), "doc_aaaaaaaaaaaa"))["text"] == 2   # 3rd attempt succeeds
+    eng.collections[0].fail_next = 3
+    with pytest.raises(RuntimeError):
+        run(m.embed_and_store(summaries(2), "doc_bbbbbbbbbbbb"))
+
+
+# ---------------------------------------------------------------- query (:539-617)
+def test_query_shape_order_and_errors():
+    m, eng = manager()
+    run(m.embed_and_store(summaries(12), "doc_aaaaaaaaaaaa"))
+    r = run(m.query("summary number 3", n_results=5))
+    assert set(r) == {"ids", "distances", "metadatas", "documents"}
+    assert r["ids"][0] == "doc_aaaaaaaaaaaa_text_3" and abs(r["distances"][0]) < 1e-6
+    assert r["distances"] == sorted(r["distances"]) and len(r["ids"]) == 5
+    assert len(run(m.query("anything", n_results=20))["ids"]) == 12         # fewer than k rows
+    for bad in ("", "   "):
+        with pytest.raises(ValueError, match="Query text cannot be empty"):
+            run(m.query(bad))
+    assert m.stats["total_queries"] == 2
+    eng.collections[0].fail_next = 3
+    with pytest.raises(RuntimeError):
+        run(m.query("x"))
+
+
+def test_batch_query_is_one_encode_and_keeps_error_dicts():
+    m, eng = manager()
+    run(m.embed_and_store(summaries(6), "doc_aaaaaaaaaaaa"))
+    eng.calls.clear()
+    run(m.clear_cache())
+    out = run(m.batch_query(["summary number 1", "", "summary number 4"], n_results=2))
+    assert eng.calls == [2]                                # one batch for the two valid queries
+    assert out[0]["ids"][0].endswith("text_1") and out[2]["ids"][0].endswith("text_4")
+    assert out[1] == {"ids": [], "distances": [], "metadatas": [], "documents": [],
+                      "error": "Query text cannot be empty"}
+    assert run(m.batch_query([])) == []
+    singles = [run(m.query(q, 2)) for q in ("summary number 1", "summary number 4")]
+    assert [o["ids"] for o in (out[0], out[2])] == [s["ids"] for s in singles]
+
+
+def test_delete_similar_stats_rerank():
+    m, eng = manager()
+    run(m.embed_and_store(summaries(5), "doc_aaaaaaaaaaaa"))
+    run(m.embed_and_store(summaries(3), "doc_bbbbbbbbbbbb"))
+    sim = run(m.get_similar_documents("doc_aaaaaaaaaaaa", "text_2", n_results=3))
+    assert "doc_aaaaaaaaaaaa_text_2" not in sim["ids"] and len(sim["ids"]) == 3
+    assert sim["ids"][0] == "doc_bbbbbbbbbbbb_text_2"     # identical summary text in the other doc
+    with pytest.raises(ValueError, match="Item not found"):
+        run(m.get_similar_documents("doc_zz", "nope"))
+    run(m.delete_document("doc_aaaaaaaaaaaa"))
+    st = run(m.get_collection_stats())
+    assert st["count"] == 3 and st["embedding_dim"] == 32 and st["batch_size"] == 32
+    assert set(st) == {"name", "count", "model", "device", "embedding_dim", "batch_size", "stats", "cache"}
+    assert run(m.get_stats()) == st
+    res = run(m.query("summary number 1", 3))
+    assert run(m.rerank_results("q", res, top_k=1))["ids"] == res["ids"][:1]
+    run(m.delete_all_documents())
+    assert run(m.get_collection_stats())["count"] == 0 and m.cache.get_stats()["size"] == 0
+    assert run(m.query("summary number 1"))["ids"] == []
+    run(m.cleanup())
+    assert not m.is_initialized and m.get_embedding_dimension() == 384     # default (:734)
+
+
+# ---------------------------------------------------------------- retriever
+def test_item_id_to_key_kats():
+    r = MultiVectorRetriever()
+    assert r._item_id_to_redis_key("doc_abc123_chunk_0_a1b2c3") == "doc:doc_abc123:chunk_0_a1b2c3"  # docstring KAT
+    assert r._item_id_to_redis_key("doc_abc") == "doc:doc_abc"
+    assert r._item_id_to_redis_key("doc_5a0ed15f2e79_text_0") == "doc:doc_5a0ed15f2e79:text_0"
+    for s in ("a", "a_b", "a_b_c", "doc_x_y_z_w"):
+        assert r._item_id_to_redis_key(s) == H.item_id_to_store_key(s)
+
+
+def test_retriever_store_retrieve_delete_payload_format():
+    kv = InProcessKV()
+    r = MultiVectorRetriever(store=kv)
+    s = [{"id": "text_0", "summary": "s0", "raw": "RAW TEXT", "type": "text", "metadata": {"x": 1}},
+         {"id": "image_1", "summary": "an image", "raw": "QkFTRTY0", "type": "image", "path": "/f/p.png"},
+         {"id": "table_0", "summary": "tbl", "raw": "|a|b|", "type": "table"}]
+    run(r.store_raw_documents("doc_abcdefabcdef", s, "f.txt"))
+    stored = json.loads(gzip.decompress(kv.get("doc:doc_abcdefabcdef:image_1")))
+    assert stored == {"id": "image_1", "type": "image", "raw": "QkFTRTY0", "summary": "an image", "path": "/f/p.png"}
+    assert json.loads(kv.get("doc_index:doc_abcdefabcdef")) == ["text_0", "image_1", "table_0"]
+    meta = json.loads(kv.get("doc_meta:doc_abcdefabcdef"))
+    assert meta["chunks"] == {"text": 1, "table": 1, "image": 1} and meta["compressed"] is True
+    ids = ["doc_abcdefabcdef_table_0", "doc_abcdefabcdef_text_0", "doc_missing_x", "doc_abcdefabcdef_image_1"]
+    out = run(r.retrieve_raw_documents(ids))
+    assert out == {"text_chunks": ["RAW TEXT"], "table_chunks": ["|a|b|"], "image_chunks": ["QkFTRTY0"]}
+    run(r.retrieve_raw_documents(ids))
+    assert r.stats["cache_hits"] == 3 and r.stats["total_retrieved"] == 8
+    assert run(r.retrieve_raw_documents([])) == {"text_chunks": [], "table_chunks": [], "image_chunks": []}
+    assert [d["doc_id"] for d in run(r.list_all_documents())] == ["doc_abcdefabcdef"]
+    assert run(r.health_check())["healthy"] is True
+    st = run(r.get_stats())
+    assert st["features"] == {"compression": True, "cache": True} and 0 < st["compression"]["ratio"]
+    run(r.delete_document("doc_abcdefabcdef"))
+    assert kv.scan_iter("doc*") == [] and run(r.retrieve_raw_documents(ids))["text_chunks"] == []
+
+
+# ---------------------------------------------------------------- chunker (parser.py:1702-1736)
+def test_chunker_sample_document_is_one_chunk(golden_dir):
+    raw = open(os.path.join(golden_dir, "sample_document.txt"), "rb").read()
+    text = raw.decode("utf-8")
+    assert len(text) == 579 and len(text.replace("\r\n", "\n")) == 563
+    chunks = ingest.basic_chunk_text(text, 1000, 200)
+    assert len(chunks) == 1 and chunks[0] == text.strip()
+    assert chunks == H.basic_chunk_text(text)
+
+
+def test_chunker_boundaries_hand_computed():
+    s = ("a" * 598 + ". ") + ("b" * 598 + ". ") + ("c" * 400)      # sentence ends at 600 and 1200
+    chunks = ingest.basic_chunk_text(s, 1000, 200)
+    # window 0 = [0,1000): last '. ' at index 598 > 500 -> chunk = s[:599], next start = 599 - 200
+    assert chunks[0] == "a" * 598 + "."
+    assert chunks[1].startswith("a" * 199 + ". " + "b" * 10) and chunks[1].endswith("b.")
+    assert chunks == H.basic_chunk_text(s, 1000, 200)
+    assert ingest.basic_chunk_text("   \n ") == [] and ingest.basic_chunk_text("") == []
+    no_boundary = "x" * 2500
+    got = ingest.basic_chunk_text(no_boundary, 1000, 200)
+    assert [len(c) for c in got] == [1000, 1000, 900, 100] and got == H.basic_chunk_text(no_boundary)
+    assert ingest.fallback_summary("x" * 10, 300) == "x" * 10 == H.fallback_summary("x" * 10, 300)
+    long = "First sentence here. " * 30
+    assert ingest.fallback_summary(long, 300) == H.fallback_summary(long, 300) and ingest.fallback_summary(long, 300).endswith(".")
+    assert ingest.fallback_summary("", 10) == "Content unavailable"

@@ -1,0 +1,38 @@
+"""CPU: WordPiece restatement vs transformers.BertTokenizer on a locally built vocabulary."""
+import pytest
+
+from multimodal_rag_amd.tokenizer import HashTokenizer, WordPieceTokenizer, basic_tokenize
+
+VOCAB = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [
+    "machine", "learning", "la", "gi", "?", "!", ",", ".", "un", "##aff", "##able", "##ing", "run", "##s",
+    "the", "quick", "brown", "fox", "cafe", "naive", "你", "好", "-", "state", "of", "art", "##ly", "embed", "##ding"]
+TEXTS = ["Machine learning là gì?", "The quick brown fox runs.", "unaffable running, naïve café!",
+         "state-of-the-art embeddingly 你好", "", "   ", "xyzzy " * 3, "a" * 120]
+
+
+def test_basic_tokenize_examples():
+    assert basic_tokenize("Hello, World!") == ["hello", ",", "world", "!"]
+    assert basic_tokenize("naïve café") == ["naive", "cafe"]
+    assert basic_tokenize("你好") == ["你", "好"]
+
+
+def test_wordpiece_matches_transformers(tmp_path):
+    transformers = pytest.importorskip("transformers")
+    p = tmp_path / "vocab.txt"
+    p.write_text("\n".join(VOCAB) + "\n", encoding="utf-8")
+    ref = transformers.BertTokenizer(str(p), do_lower_case=True)
+    mine = WordPieceTokenizer.from_vocab_file(str(p))
+    for t in TEXTS:
+        want = ref(t, truncation=True, max_length=32)["input_ids"]
+        assert mine.encode(t, 32) == want, t
+    long = "the quick brown fox " * 50
+    assert mine.encode(long, 16) == ref(long, truncation=True, max_length=16)["input_ids"]
+
+
+def test_hash_tokenizer_is_deterministic_and_in_range():
+    t = HashTokenizer(30522)
+    a = t.encode("Machine learning là gì?", 256)
+    assert a == t.encode("machine LEARNING la gi ?", 256)
+    assert a[0] == 101 and a[-1] == 102 and all(1000 <= x < 30522 for x in a[1:-1])
+    assert len(t.encode("word " * 1000, 256)) == 256
+    assert t.encode("", 256) == [101, 102]
