@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-embed", action="store_true")
+    ap.add_argument("--merge", choices=["host", "device"], default="host",
+                    help="where the G*k -> k merge runs for N > 1 (north star: host)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal on a one-GPU box (collective on host copies); the driver uses nccl (RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +98,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -101,7 +106,10 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from multimodal_rag_amd import _native as N
 
@@ -116,46 +124,30 @@ def main():
     corpus = make_unit_rows(lo, hi, DIM, ld, dtype, dev, base_seed=1234)
     q = make_unit_rows(0, B, DIM, ld, dtype, dev, base_seed=987654)
     ws = torch.empty(N.cosine_topk_workspace_bytes(B, n_local, k) + 16, dtype=torch.uint8, device=dev)
-    loc_s = torch.empty((B, k), dtype=torch.float32, device=dev)
-    loc_r = torch.empty((B, k), dtype=torch.int64, device=dev)
-    if world > 1:
-        all_s = torch.empty((world, B, k), dtype=torch.float32, device=dev)
-        all_r = torch.empty((world, B, k), dtype=torch.int64, device=dev)
-    else:
-        all_s, all_r = loc_s.view(1, B, k), loc_r.view(1, B, k)
-    host_s = [torch.empty((world, B, k), dtype=torch.float32).pin_memory() for _ in range(2)]
-    host_r = [torch.empty((world, B, k), dtype=torch.int64).pin_memory() for _ in range(2)]
-    copied = [torch.cuda.Event() for _ in range(2)]
-    final = {}
+    events = {}
 
-    def device_step(i, ev=None):
+    def local_search(slot, out_s, out_r):
+        ev = events.get(slot)
         if ev is not None:
             ev[0].record()
         N.cosine_topk_lists(q, corpus, n_local, DIM, k, ws)
         if ev is not None:
             ev[1].record()
-        N.cosine_topk_select(B, n_local, k, lo, ws, loc_s, loc_r)
-        if world > 1:
-            dist.all_gather_into_tensor(all_s, loc_s)
-            dist.all_gather_into_tensor(all_r, loc_r)
-        host_s[i & 1].copy_(all_s, non_blocking=True)
-        host_r[i & 1].copy_(all_r, non_blocking=True)
-        copied[i & 1].record()
+        N.cosine_topk_select(B, n_local, k, lo, ws, out_s, out_r)
 
-    def host_finish(i):
-        copied[i & 1].synchronize()
-        if world > 1:
-            final["s"], final["r"] = N.merge_topk_host(host_s[i & 1], host_r[i & 1], k)
-        else:
-            final["s"], final["r"] = host_s[i & 1][0], host_r[i & 1][0]
+    from multimodal_rag_amd.sharded import ShardedSearch
 
-    def run(steps, events=None):
+    ss = ShardedSearch(B, k, world, rank, dev, local_search, merge=args.merge,
+                       collective_on_host=(args.dist_backend == "gloo"))
+    final = {}
+
+    def run(steps):
         for i in range(steps):
-            device_step(i, events[i] if events is not None else None)
+            ss.launch(i)
             if i > 0:
-                host_finish(i - 1)  # overlaps the device work of step i
+                final["s"], final["r"] = ss.finish(i - 1)  # overlaps the device work of step i
         if steps:
-            host_finish(steps - 1)
+            final["s"], final["r"] = ss.finish(steps - 1)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -164,22 +156,26 @@ def main():
             torch.cuda.synchronize()
 
     run(args.warmup)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for i in range(args.steps):
+        events[i] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     sync_all()
     t0 = time.perf_counter()
-    run(args.steps, events)
+    run(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else float("nan")
     gpu_s = final["s"].clone().numpy()
     gpu_r = final["r"].clone().numpy()
 
     result = None
     if rank == 0:
+        import hashlib
+
+        rows_md5 = hashlib.md5(np.ascontiguousarray(gpu_r).tobytes()).hexdigest()  # identical for every N
         qps = B * args.steps / dt
         alg_bytes = n_local * DIM * 2  # corpus read once per query batch, per GPU
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -209,9 +205,9 @@ def main():
             "config": {
                 "workload": f"retrieve: {n_total}x{DIM} fp16 unit-norm corpus row-sharded over {world} GPU(s), "
                             f"query batch {B}, top_k={k}, exact cosine (fp32 accumulate), "
-                            f"{'RCCL all-gather + host merge' if world > 1 else 'single shard'}, results to host",
+                            f"{(('RCCL' if args.dist_backend == 'nccl' else 'gloo (rehearsal)') + ' all-gather + ' + args.merge + ' merge') if world > 1 else 'single shard'}, results to host",
                 "corpus_rows": n_total, "dim": DIM, "batch": B, "top_k": k, "rows_per_gpu": n_local,
-                "parallelism": f"row-shard x{world}",
+                "parallelism": f"row-shard x{world}", "result_rows_md5": rows_md5,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "cosine_topk_kernel",

@@ -1,0 +1,103 @@
+"""Row-sharded search across the GPUs of one node.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The corpus matrix
+is split row-wise: rank g owns global rows [g*ceil(N/G), (g+1)*ceil(N/G)).  A query batch is
+present on every rank; each rank runs the fused GEMM + top-k kernel on its shard, the per-rank
+[B, k] (score, global row) blocks are exchanged by ONE all-gather each (15-61 KB per rank:
+latency-bound, not link-bound), and the G*k candidates per query are merged to k on the host
+(north star; identical C++ ordering rule as the device merge: score desc, lower global row on
+ties).  Because the global top-k is a subset of the union of shard top-k, the result is
+identical for every G.
+
+The reference is single-process (no collective anywhere), so nothing here
+replaces reference code; it is the exchange step the row-sharded index needs.
+
+`launch()` enqueues the device work of one query batch and returns immediately; `finish()`
+waits for that batch's copy and merges on the host, so callers can overlap batch i+1's device
+work with batch i's merge (two buffers).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+
+def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range [lo, hi) of `rank` (SURVEY.md section 8e partitioning)."""
+    per = (n_total + world - 1) // world
+    return min(n_total, rank * per), min(n_total, (rank + 1) * per)
+
+
+class ShardedSearch:
+    def __init__(self, batch: int, k: int, world: int, rank: int, device: torch.device,
+                 local_search: Callable[[int, torch.Tensor, torch.Tensor], None],
+                 group: Optional[dist.ProcessGroup] = None, merge: str = "host",
+                 collective_on_host: bool = False):
+        """local_search(slot, out_scores [B,k] f32, out_rows [B,k] i64) must enqueue / perform this
+        rank's shard search with GLOBAL row ids (-1 / -inf padding)."""
+        if merge not in ("host", "device"):
+            raise ValueError("merge must be 'host' or 'device'")
+        self.B, self.k, self.world, self.rank = batch, k, world, rank
+        self.device = torch.device(device)
+        self.group = group
+        self.merge = merge
+        self.local_search = local_search
+        # rehearsal mode (gloo on a one-GPU box): the all-gather runs on host copies
+        self.collective_on_host = collective_on_host and world > 1
+        on_gpu = self.device.type == "cuda"
+        self.loc_s = torch.empty((batch, k), dtype=torch.float32, device=self.device)
+        self.loc_r = torch.empty((batch, k), dtype=torch.int64, device=self.device)
+        if world > 1:
+            self.all_s = torch.empty((world, batch, k), dtype=torch.float32, device=self.device)
+            self.all_r = torch.empty((world, batch, k), dtype=torch.int64, device=self.device)
+        else:
+            self.all_s, self.all_r = self.loc_s.view(1, batch, k), self.loc_r.view(1, batch, k)
+        mk = (lambda dt: torch.empty((world, batch, k), dtype=dt).pin_memory()) if on_gpu else (
+            lambda dt: torch.empty((world, batch, k), dtype=dt))
+        self.host_s = [mk(torch.float32) for _ in range(2)]
+        self.host_r = [mk(torch.int64) for _ in range(2)]
+        self.copied = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
+        self.dev_out = [None, None]
+
+    def launch(self, slot: int):
+        """Device phase of one query batch: shard search, all-gather, async copy (or device merge)."""
+        self.local_search(slot, self.loc_s, self.loc_r)
+        if self.collective_on_host:
+            ls, lr = self.loc_s.cpu(), self.loc_r.cpu()
+            gs = torch.empty((self.world * self.B, self.k), dtype=torch.float32)
+            gr = torch.empty((self.world * self.B, self.k), dtype=torch.int64)
+            dist.all_gather_into_tensor(gs, ls, group=self.group)
+            dist.all_gather_into_tensor(gr, lr, group=self.group)
+            self.all_s.copy_(gs.view_as(self.all_s))
+            self.all_r.copy_(gr.view_as(self.all_r))
+        elif self.world > 1:
+            # output viewed as the dim-0 concatenation of the per-rank [B, k] blocks
+            dist.all_gather_into_tensor(self.all_s.view(self.world * self.B, self.k), self.loc_s, group=self.group)
+            dist.all_gather_into_tensor(self.all_r.view(self.world * self.B, self.k), self.loc_r, group=self.group)
+        b = slot & 1
+        if self.merge == "device" and self.world > 1:
+            s, r = _native.merge_topk(self.all_s, self.all_r, self.k)
+            self.host_s[b][0].copy_(s, non_blocking=True)
+            self.host_r[b][0].copy_(r, non_blocking=True)
+        else:
+            self.host_s[b].copy_(self.all_s, non_blocking=True)
+            self.host_r[b].copy_(self.all_r, non_blocking=True)
+        if self.copied is not None:
+            self.copied[b].record()
+
+    def finish(self, slot: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Host phase: wait for the batch's copy, merge G*k -> k per query.  Returns CPU tensors."""
+        b = slot & 1
+        if self.copied is not None:
+            self.copied[b].synchronize()
+        if self.world > 1 and self.merge == "host":
+            return _native.merge_topk_host(self.host_s[b], self.host_r[b], self.k)
+        return self.host_s[b][0], self.host_r[b][0]
+
+    def search(self, slot: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        self.launch(slot)
+        return self.finish(slot)
