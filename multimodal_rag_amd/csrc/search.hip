@@ -15,7 +15,8 @@
 //   * MFMA orientation D[corpus row][query] = A(corpus) x B(Q^T): the query sits on the
 //     lane (col = lane & 31), corpus rows sit in the 16 accumulator registers, so top-k
 //     selection per query is lane-local register work with no cross-lane traffic;
-//   * 8 waves = WM x WN; each wave owns 32 queries x (256/WM) corpus rows;
+//   * NW waves = WM x WN (8 waves, or 16 = 4 per SIMD for the 256-query shape: the extra waves
+//     hide LDS-read and barrier latency); each wave owns 32 queries x (256/WM) corpus rows;
 //   * selection: each lane keeps a sorted K-list (score desc) for its query over the rows it
 //     sees; an element enters only if it beats a running threshold (k-th best of the union
 //     of the two half-wave lists of that query) -- after the first tiles almost nothing does;
@@ -26,6 +27,7 @@
 #include "mmrag_internal.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 using namespace mmrag;
 
@@ -39,7 +41,6 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 constexpr int TM = 256;            // corpus rows per tile
 constexpr int SLAB = 128;          // bytes of K per row per stage
-constexpr int NTHREADS = 512;
 constexpr int CORPUS_STAGE = TM * SLAB;  // 32 KiB
 constexpr float NEG_INF = -__builtin_inff();
 
@@ -111,15 +112,17 @@ struct KParams {
     int n_lists;          // gridDim.x * WM * 2
 };
 
-template <int DT, int WN, int K, int NSTAGE>
-__global__ __launch_bounds__(NTHREADS, 2) void cosine_topk_kernel(const KParams p) {
+template <int DT, int WN, int K, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // amdgcn builtins below: the host pass only needs the launch stub
-    constexpr int WM = 8 / WN;           // waves along corpus rows
+    constexpr int WM = NW / WN;          // waves along corpus rows
     constexpr int RM = 8 / WM;           // 32-row blocks per wave  (== WN)
     constexpr int QROWS = 32 * WN;
     constexpr int STAGE = CORPUS_STAGE + QROWS * SLAB;
-    constexpr int QLOADS = WN / 2;       // 1 KiB DMA instructions per wave for the Q slab
-    constexpr int LOADS = 4 + QLOADS;    // per wave per ring item
+    constexpr int CLOADS = 32 / NW;      // 1 KiB DMA instructions per wave for the corpus slab
+    constexpr int QLOADS = (4 * WN) / NW; // ... and for the Q slab
+    constexpr int LOADS = CLOADS + QLOADS;  // per wave per ring item
+    static_assert(CLOADS >= 1 && QLOADS >= 1 && CLOADS * NW == 32 && QLOADS * NW == 4 * WN, "piece split");
     static_assert(WN == 2 || WN == 4 || WN == 8, "WN");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "NSTAGE");
     static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void cosine_topk_kernel(const KParams 
     // per-lane source offsets (row * RB + swizzled chunk * 16) for this wave's DMA instructions
     const int dma_row = lane >> 3;        // row inside an 8-row (1 KiB) LDS piece
     const int dma_slot = lane & 7;        // 16-byte slot inside the 128-byte LDS row
-    unsigned c_off[4];
+    unsigned c_off[CLOADS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + dma_row;
+    for (int i = 0; i < CLOADS; ++i) {
+        const int row = (wave * CLOADS + i) * 8 + dma_row;
         c_off[i] = (unsigned)row * RB + (unsigned)((dma_slot ^ ((row >> 1) & 7)) * 16);
     }
     unsigned q_off[QLOADS];
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void cosine_topk_kernel(const KParams 
         char *st = smem + stage_idx * STAGE;
         const unsigned koff = (unsigned)is_k * SLAB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + (wave * 4 + i) * 1024), 16,
+        for (int i = 0; i < CLOADS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + (wave * CLOADS + i) * 1024), 16,
                                                      c_off[i] + koff, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < QLOADS; ++i)
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cosine_topk_kernel(const KParams 
     // ---- write this lane's list ---------------------------------------------------------------
     const int q = q0 + wn * 32 + r32;
     if (q < p.B) {
-        const int list = ((int)blockIdx.x * WM + wm) * 2 + h;
+        const int list = ((int)blockIdx.x * WM + wm) * 2 + h;  // WM lists-pairs per workgroup
         const size_t base = ((size_t)q * p.n_lists + list) * K;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
 struct Plan {
     int K;        // list depth: 5, 10 or 20
     int WN;       // waves along queries
+    int NW;       // waves per workgroup
     int grid_x, grid_y;
     int n_tiles;
     int n_lists;
@@ -456,14 +460,15 @@ Plan make_plan(int B, long long n, int k) {
     const int cus = num_cus();
     pl.grid_x = pl.n_tiles < cus ? pl.n_tiles : cus;
     if (pl.grid_x < 1) pl.grid_x = 1;
-    pl.n_lists = pl.grid_x * (8 / pl.WN) * 2;
+    pl.NW = (pl.K == 5 && pl.WN == 8 && !getenv("MMRAG_NW8")) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
+    pl.n_lists = pl.grid_x * (pl.NW / pl.WN) * 2;
     pl.b_pad = pl.grid_y * qrows;
     return pl;
 }
 
-template <int DT, int WN, int K, int NSTAGE>
+template <int DT, int WN, int K, int NSTAGE, int NW = 8>
 void launch_main(const KParams &p, dim3 grid, hipStream_t s) {
-    cosine_topk_kernel<DT, WN, K, NSTAGE><<<grid, NTHREADS, 0, s>>>(p);
+    cosine_topk_kernel<DT, WN, K, NSTAGE, NW><<<grid, 64 * NW, 0, s>>>(p);
 }
 
 template <int DT>
@@ -472,6 +477,7 @@ int dispatch_main(const Plan &pl, const KParams &p, hipStream_t s) {
     if (pl.K == 5) {
         if (pl.WN == 2) launch_main<DT, 2, 5, 3>(p, grid, s);
         else if (pl.WN == 4) launch_main<DT, 4, 5, 3>(p, grid, s);
+        else if (pl.NW == 16) launch_main<DT, 8, 5, 2, 16>(p, grid, s);
         else launch_main<DT, 8, 5, 2>(p, grid, s);
     } else if (pl.K == 10) {
         launch_main<DT, 2, 10, 3>(p, grid, s);
