@@ -1,0 +1,23 @@
+"""A/B the linear kernel configs in ONE process (MMRAG_LINEAR_CFG is read once per process, so
+each config runs in a child... no: read per call here via re-exec is not possible; the C side
+caches it, so this script is started once per config by the shell and prints comparable numbers
+against a fixed reference config measured in the same process: torch.matmul (rocBLAS)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_rag_amd import _native as N
+def t(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+M = 65536
+for K, Nf in [(768, 2304), (768, 768), (768, 3072), (3072, 768)]:
+    x = (torch.randn((M, K), device="cuda") * 0.5).half(); w = (torch.randn((Nf, K), device="cuda") * 0.05).half()
+    b = torch.randn(Nf, device="cuda"); out = torch.empty((M, Nf), dtype=torch.float16, device="cuda")
+    fl = 2.0 * M * K * Nf
+    mine = sorted(t(lambda: N.linear_f16(x, w, b, 0, None, out)) for _ in range(3))[1]
+    ref = sorted(t(lambda: torch.matmul(x, w.t())) for _ in range(3))[1]
+    print(f"cfg={os.environ.get('MMRAG_LINEAR_CFG','0')} K={K} N={Nf}: mine {mine:.1f} us {fl/mine/1e6:.0f} TF | rocBLAS {ref:.1f} us {fl/ref/1e6:.0f} TF", flush=True)
