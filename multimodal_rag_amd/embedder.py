@@ -183,6 +183,9 @@ class EmbeddingManager:
 
     async def cleanup(self):
         """embedder.py:250-264."""
+        if getattr(self, "_dispatcher", None) is not None:
+            await self._dispatcher.stop()
+            self._dispatcher = None
         if self._engine is not None and hasattr(self._engine, "release"):
             self._engine.release()
         self.client = None
@@ -300,12 +303,22 @@ class EmbeddingManager:
                 await self._sleep(wait_time)
 
     # ------------------------------------------------------------------ query ---------------
+    def enable_dynamic_batching(self, max_batch: int = 256, max_wait_ms: float = 2.0):
+        """Route query() through a micro-batching dispatcher (not in the reference):
+        concurrent single queries are served by one batched encode + one batched search."""
+        from .dispatcher import QueryDispatcher
+
+        self._dispatcher = QueryDispatcher(self.batch_query, max_batch=max_batch, max_wait_ms=max_wait_ms)
+        return self._dispatcher
+
     async def query(self, query_text: str, n_results: int = 5, filter_dict: Optional[Dict] = None) -> Dict[str, Any]:
         """embedder.py:539-583."""
         if not self.is_initialized:
             await self.initialize()
         if not query_text or not query_text.strip():
             raise ValueError("Query text cannot be empty")
+        if getattr(self, "_dispatcher", None) is not None:
+            return await self._dispatcher.submit(query_text, n_results, filter_dict)
         try:
             query_embeddings = await self.embed_texts_batch([query_text])
             results = await self._query_with_retry(query_embedding=query_embeddings[0], n_results=n_results,

@@ -212,3 +212,24 @@ def test_chunker_boundaries_hand_computed():
     long = "First sentence here. " * 30
     assert ingest.fallback_summary(long, 300) == H.fallback_summary(long, 300) and ingest.fallback_summary(long, 300).endswith(".")
     assert ingest.fallback_summary("", 10) == "Content unavailable"
+
+
+# ---------------------------------------------------------------- dynamic batching dispatcher
+def test_dispatcher_batches_concurrent_queries():
+    async def main():
+        m, eng = manager(enable_cache=False)
+        await m.embed_and_store(summaries(40), "doc_aaaaaaaaaaaa")
+        singles = [await m.query(f"summary number {i}", 3) for i in range(40)]
+        eng.calls.clear()
+        d = m.enable_dynamic_batching(max_batch=64, max_wait_ms=20)
+        outs = await asyncio.gather(*[m.query(f"summary number {i}", 3) for i in range(40)])
+        assert [o["ids"] for o in outs] == [s["ids"] for s in singles]
+        assert len(eng.calls) <= 3 and sum(eng.calls) == 40          # batched encodes instead of 40
+        assert d.stats["requests"] == 40 and d.stats["max_batch_seen"] >= 20
+        mixed = await asyncio.gather(m.query("summary number 1", 2), m.query("summary number 2", 5),
+                                     return_exceptions=True)
+        assert len(mixed[0]["ids"]) == 2 and len(mixed[1]["ids"]) == 5   # grouped per k
+        with pytest.raises(ValueError):
+            await m.query("  ")
+        await m.cleanup()
+    run(main())

@@ -1,0 +1,100 @@
+"""WAL reader / replay (CPU, synthetic sqlite in Chroma's schema + the committed WAL-70 fixture)
+and save/load of the GPU index (gpu)."""
+import json
+import os
+import sqlite3
+
+import numpy as np
+import pytest
+
+from multimodal_rag_amd import persistence as P
+from tests.fakes import FakeCollection
+
+SCHEMA = """CREATE TABLE embeddings_queue (seq_id INTEGER PRIMARY KEY, created_at TIMESTAMP NOT NULL DEFAULT
+CURRENT_TIMESTAMP, operation INTEGER NOT NULL, topic TEXT NOT NULL, id TEXT NOT NULL, vector BLOB, encoding TEXT,
+metadata TEXT)"""
+
+
+def make_db(path, wal70, upto=None):
+    con = sqlite3.connect(path)
+    con.execute(SCHEMA)
+    row_of = {s: i for i, s in enumerate(wal70["ids"])}
+    for seq, op, rid in wal70["log"][:upto]:
+        if op == 0:
+            i = row_of[rid]
+            meta = dict(wal70["metadatas"][i], **{"chroma:document": f"text of {rid}", "has_raw": "true"})
+            con.execute("insert into embeddings_queue (seq_id, operation, topic, id, vector, encoding, metadata) "
+                        "values (?,?,?,?,?,?,?)", (seq, op, "t", rid, wal70["vectors"][i].astype("<f4").tobytes(),
+                                                   "FLOAT32", json.dumps(meta)))
+        else:
+            con.execute("insert into embeddings_queue (seq_id, operation, topic, id) values (?,?,?,?)", (seq, op, "t", rid))
+    con.commit()
+    con.close()
+
+
+def test_wal_reader_and_replay_full_log(tmp_path, wal70):
+    db = str(tmp_path / "chroma.sqlite3")
+    make_db(db, wal70)
+    recs = list(P.read_chroma_wal(db))
+    assert len(recs) == 140 and [r.seq_id for r in recs] == sorted(r.seq_id for r in recs)
+    adds = [r for r in recs if r.operation == P.OP_ADD]
+    assert len(adds) == 70 and adds[0].vector.shape == (384,) and adds[0].document.startswith("text of ")
+    assert "chroma:document" not in adds[0].metadata and adds[0].metadata["doc_id"].startswith("doc_")
+    col = FakeCollection(384)
+    counts = P.replay_wal(col, recs, batch=16)
+    assert counts == {"add": 70, "delete": 70, "update": 0, "skipped": 0}
+    assert col.count() == 0          # the committed log deletes everything it added
+
+
+def test_wal_replay_prefix_leaves_live_rows(tmp_path, wal70):
+    db = str(tmp_path / "c.sqlite3")
+    make_db(db, wal70, upto=60)
+    col = FakeCollection(384)
+    P.replay_wal(col, P.read_chroma_wal(db))
+    live = {}
+    for seq, op, rid in wal70["log"][:60]:
+        if op == 0:
+            live[rid] = True
+        else:
+            live.pop(rid, None)
+    assert sorted(col.ids) == sorted(live)
+    row_of = {s: i for i, s in enumerate(wal70["ids"])}
+    i = col.ids.index(next(iter(live)))
+    assert np.array_equal(col.vecs[i], wal70["vectors"][row_of[col.ids[i]]])
+
+
+@pytest.mark.gpu
+def test_index_save_load_roundtrip(tmp_path, wal70):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodal_rag_amd.index import VectorIndex
+
+    idx = VectorIndex(384, dtype=torch.float16)
+    idx.add(wal70["vectors"], [f"d{i}" for i in range(70)], wal70["metadatas"], wal70["ids"])
+    before = idx.query(wal70["vectors"][:9], n_results=5)
+    P.save_index(idx, str(tmp_path / "ix"))
+    idx2 = P.load_index(str(tmp_path / "ix"))
+    assert idx2.count() == 70 and torch.equal(idx2.matrix[:70], idx.matrix[:70])
+    assert idx2.query(wal70["vectors"][:9], n_results=5) == before
+    assert idx2.get(ids=[wal70["ids"][3]])["documents"] == ["d3"]
+
+
+@pytest.mark.gpu
+def test_wal_replay_into_gpu_index(tmp_path, wal70):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodal_rag_amd.index import VectorIndex
+
+    db = str(tmp_path / "c.sqlite3")
+    make_db(db, wal70, upto=100)
+    idx = VectorIndex(384, dtype=torch.float32)
+    P.replay_wal(idx, P.read_chroma_wal(db), batch=8)
+    ref = FakeCollection(384)
+    P.replay_wal(ref, P.read_chroma_wal(db))
+    assert sorted(idx.get()["ids"]) == sorted(ref.ids) and idx.count() == ref.count() > 0
+    q = wal70["vectors"][:5]
+    assert idx.query(q, n_results=3)["ids"] == ref.query(q, n_results=3)["ids"]
