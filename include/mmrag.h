@@ -93,6 +93,10 @@ int mmrag_merge_topk(const float *scores, const int64_t *rows, int G, int B, int
                      float *out_scores, int64_t *out_rows, void *stream);
 int mmrag_merge_topk_host(const float *scores, const int64_t *rows, int G, int B, int k_in,
                           int k, float *out_scores, int64_t *out_rows);
+/* Same merge over G rank blocks laid out [rows B*k_in i64 | scores B*k_in f32 | pad to 8 bytes]
+ * each, i.e. the result of ONE all-gather of a packed per-rank buffer. */
+int mmrag_merge_topk_host_packed(const void *blocks, int G, int B, int k_in, int k,
+                                 float *out_scores, int64_t *out_rows);
 
 /* ---------------------------------------------------------------------------------------
  * Store.  Replaces chromadb's  collection.add(embeddings=..., ...)  vector half

@@ -49,6 +49,8 @@ def _declare(lib):
     lib.mmrag_merge_topk.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.mmrag_merge_topk_host.restype = c_int
     lib.mmrag_merge_topk_host.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.mmrag_merge_topk_host_packed.restype = c_int
+    lib.mmrag_merge_topk_host_packed.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.mmrag_append_rows.restype = c_int
     lib.mmrag_append_rows.argtypes = [c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_int64, c_int, c_void_p]
     lib.mmrag_gather_rows.restype = c_int
@@ -176,6 +178,21 @@ def merge_topk_host(scores: torch.Tensor, rows: torch.Tensor, k: int) -> Tuple[t
     st = lib().mmrag_merge_topk_host(scores.data_ptr(), rows.data_ptr(), G, B, k_in, k, out_s.data_ptr(),
                                      out_r.data_ptr())
     _check(st, "mmrag_merge_topk_host")
+    return out_s, out_r
+
+
+def packed_block_bytes(B: int, k: int) -> int:
+    return (B * k * 12 + 7) // 8 * 8
+
+
+def merge_topk_host_packed(blocks: torch.Tensor, G: int, B: int, k_in: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host merge of G packed rank blocks [rows B*k_in i64 | scores B*k_in f32 | pad to 8 B] (CPU uint8)."""
+    if blocks.is_cuda or blocks.dtype != torch.uint8 or blocks.numel() != G * packed_block_bytes(B, k_in):
+        raise MMRagNativeError("merge_topk_host_packed takes a CPU uint8 tensor of G * packed_block_bytes(B, k_in) bytes")
+    out_s = torch.empty((B, k), dtype=torch.float32)
+    out_r = torch.empty((B, k), dtype=torch.int64)
+    st = lib().mmrag_merge_topk_host_packed(blocks.data_ptr(), G, B, k_in, k, out_s.data_ptr(), out_r.data_ptr())
+    _check(st, "mmrag_merge_topk_host_packed")
     return out_s, out_r
 
 

@@ -3,7 +3,7 @@
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The corpus matrix
 is split row-wise: rank g owns global rows [g*ceil(N/G), (g+1)*ceil(N/G)).  A query batch is
 present on every rank; each rank runs the fused GEMM + top-k kernel on its shard, the per-rank
-[B, k] (score, global row) blocks are exchanged by ONE all-gather each (15-61 KB per rank:
+[B, k] (score, global row) blocks are packed into one buffer and exchanged by ONE all-gather (15-61 KB per rank:
 latency-bound, not link-bound), and the G*k candidates per query are merged to k on the host
 (north star; identical C++ ordering rule as the device merge: score desc, lower global row on
 ties).  Because the global top-k is a subset of the union of shard top-k, the result is
@@ -49,43 +49,43 @@ class ShardedSearch:
         # rehearsal mode (gloo on a one-GPU box): the all-gather runs on host copies
         self.collective_on_host = collective_on_host and world > 1
         on_gpu = self.device.type == "cuda"
-        self.loc_s = torch.empty((batch, k), dtype=torch.float32, device=self.device)
-        self.loc_r = torch.empty((batch, k), dtype=torch.int64, device=self.device)
-        if world > 1:
-            self.all_s = torch.empty((world, batch, k), dtype=torch.float32, device=self.device)
-            self.all_r = torch.empty((world, batch, k), dtype=torch.int64, device=self.device)
-        else:
-            self.all_s, self.all_r = self.loc_s.view(1, batch, k), self.loc_r.view(1, batch, k)
-        mk = (lambda dt: torch.empty((world, batch, k), dtype=dt).pin_memory()) if on_gpu else (
-            lambda dt: torch.empty((world, batch, k), dtype=dt))
-        self.host_s = [mk(torch.float32) for _ in range(2)]
-        self.host_r = [mk(torch.int64) for _ in range(2)]
+        # ONE packed exchange buffer per rank: [rows B*k i64 | scores B*k f32 | pad] -> one all-gather per batch
+        nb = batch * k
+        self.block_bytes = _native.packed_block_bytes(batch, k)
+        self.loc = torch.empty(self.block_bytes, dtype=torch.uint8, device=self.device)
+        self.loc_r = self.loc[: nb * 8].view(torch.int64).view(batch, k)
+        self.loc_s = self.loc[nb * 8: nb * 12].view(torch.float32).view(batch, k)
+        self.all = (torch.empty(world * self.block_bytes, dtype=torch.uint8, device=self.device)
+                    if world > 1 else self.loc)
+        mk = (lambda: torch.empty(world * self.block_bytes, dtype=torch.uint8).pin_memory()) if on_gpu else (
+            lambda: torch.empty(world * self.block_bytes, dtype=torch.uint8))
+        self.host = [mk() for _ in range(2)]
         self.copied = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
-        self.dev_out = [None, None]
+
+    def _views(self, buf: torch.Tensor):
+        """[G, B, k] score / row views of a packed exchange buffer (strided over the rank blocks)."""
+        nb = self.B * self.k
+        blocks = buf.view(self.world, self.block_bytes)
+        return (blocks[:, nb * 8: nb * 12].contiguous().view(torch.float32).view(self.world, self.B, self.k),
+                blocks[:, : nb * 8].contiguous().view(torch.int64).view(self.world, self.B, self.k))
 
     def launch(self, slot: int):
         """Device phase of one query batch: shard search, all-gather, async copy (or device merge)."""
         self.local_search(slot, self.loc_s, self.loc_r)
         if self.collective_on_host:
-            ls, lr = self.loc_s.cpu(), self.loc_r.cpu()
-            gs = torch.empty((self.world * self.B, self.k), dtype=torch.float32)
-            gr = torch.empty((self.world * self.B, self.k), dtype=torch.int64)
-            dist.all_gather_into_tensor(gs, ls, group=self.group)
-            dist.all_gather_into_tensor(gr, lr, group=self.group)
-            self.all_s.copy_(gs.view_as(self.all_s))
-            self.all_r.copy_(gr.view_as(self.all_r))
+            gathered = torch.empty(self.world * self.block_bytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, self.loc.cpu(), group=self.group)
+            self.all.copy_(gathered)
         elif self.world > 1:
-            # output viewed as the dim-0 concatenation of the per-rank [B, k] blocks
-            dist.all_gather_into_tensor(self.all_s.view(self.world * self.B, self.k), self.loc_s, group=self.group)
-            dist.all_gather_into_tensor(self.all_r.view(self.world * self.B, self.k), self.loc_r, group=self.group)
+            dist.all_gather_into_tensor(self.all, self.loc, group=self.group)
         b = slot & 1
         if self.merge == "device" and self.world > 1:
-            s, r = _native.merge_topk(self.all_s, self.all_r, self.k)
-            self.host_s[b][0].copy_(s, non_blocking=True)
-            self.host_r[b][0].copy_(r, non_blocking=True)
+            s, r = _native.merge_topk(*self._views(self.all), self.k)
+            nb = self.B * self.k
+            self.host[b][nb * 8: nb * 12].view(torch.float32).view(self.B, self.k).copy_(s, non_blocking=True)
+            self.host[b][: nb * 8].view(torch.int64).view(self.B, self.k).copy_(r, non_blocking=True)
         else:
-            self.host_s[b].copy_(self.all_s, non_blocking=True)
-            self.host_r[b].copy_(self.all_r, non_blocking=True)
+            self.host[b].copy_(self.all, non_blocking=True)
         if self.copied is not None:
             self.copied[b].record()
 
@@ -95,8 +95,10 @@ class ShardedSearch:
         if self.copied is not None:
             self.copied[b].synchronize()
         if self.world > 1 and self.merge == "host":
-            return _native.merge_topk_host(self.host_s[b], self.host_r[b], self.k)
-        return self.host_s[b][0], self.host_r[b][0]
+            return _native.merge_topk_host_packed(self.host[b], self.world, self.B, self.k, self.k)
+        nb = self.B * self.k
+        return (self.host[b][nb * 8: nb * 12].view(torch.float32).view(self.B, self.k),
+                self.host[b][: nb * 8].view(torch.int64).view(self.B, self.k))
 
     def search(self, slot: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         self.launch(slot)

@@ -62,3 +62,20 @@ def test_no_cpu_fallback(native):
     q = torch.zeros((2, 384))
     with pytest.raises(native.MMRagNativeError):
         native.cosine_topk(q, q, 2, 384, 1)
+
+
+def test_packed_host_merge_matches_oracle(native):
+    from oracle import search_oracle as O
+
+    g = np.random.default_rng(1)
+    G, B, k = 3, 7, 5                      # B*k odd: exercises the 8-byte block padding
+    s = -np.sort(-g.standard_normal((G, B, k)).astype(np.float32), axis=2)
+    r = g.permutation(G * B * k).reshape(G, B, k).astype(np.int64)
+    bb = native.packed_block_bytes(B, k)
+    buf = np.zeros(G * bb, np.uint8)
+    for i in range(G):
+        buf[i * bb: i * bb + B * k * 8] = r[i].reshape(-1).view(np.uint8)
+        buf[i * bb + B * k * 8: i * bb + B * k * 12] = s[i].reshape(-1).view(np.uint8)
+    es, er = O.merge_topk(s, r, k)
+    hs, hr = native.merge_topk_host_packed(torch.from_numpy(buf), G, B, k, k)
+    assert np.array_equal(hs.numpy(), es) and np.array_equal(hr.numpy(), er)
