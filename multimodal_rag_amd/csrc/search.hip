@@ -44,6 +44,10 @@ constexpr int SLAB = 128;          // bytes of K per row per stage
 constexpr int CORPUS_STAGE = TM * SLAB;  // 32 KiB
 constexpr float NEG_INF = -__builtin_inff();
 
+__device__ inline bool better(float s, long long r, float s2, long long r2) {
+    return s > s2 || (s == s2 && r < r2);
+}
+
 template <int K>
 struct TopList {
     float v[K];
@@ -53,6 +57,21 @@ struct TopList {
         for (int i = 0; i < K; ++i) {
             v[i] = NEG_INF;
             r[i] = INT_MAX;
+        }
+    }
+    // full (score desc, row asc) order: for merging lists whose rows interleave
+    __device__ inline void insert_ordered(float x, int xr) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool b = x > v[j] || (x == v[j] && xr < r[j]);
+            const float nv = b ? x : v[j];
+            const float nx = b ? v[j] : x;
+            const int nr = b ? xr : r[j];
+            const int nxr = b ? r[j] : xr;
+            v[j] = nv;
+            x = nx;
+            r[j] = nr;
+            xr = nxr;
         }
     }
     // insertion order == row order inside a lane, so "strictly greater" keeps the lower row on ties
@@ -72,9 +91,6 @@ struct TopList {
     }
 };
 
-__device__ inline bool better(float s, long long r, float s2, long long r2) {
-    return s > s2 || (s == s2 && r < r2);
-}
 
 template <int N>
 __device__ inline void wait_vmcnt() {
@@ -109,7 +125,7 @@ struct KParams {
     int B;
     unsigned row_bytes;   // ld * esize, multiple of 128
     int n_tiles;
-    int n_lists;          // gridDim.x * WM * 2
+    int n_lists;          // gridDim.x (lists are merged per workgroup before they are written)
 };
 
 template <int DT, int WN, int K, int NSTAGE, int NW>
@@ -303,15 +319,36 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
         }
     }
 
-    // ---- write this lane's list ---------------------------------------------------------------
-    const int q = q0 + wn * 32 + r32;
-    if (q < p.B) {
-        const int list = ((int)blockIdx.x * WM + wm) * 2 + h;  // WM lists-pairs per workgroup
-        const size_t base = ((size_t)q * p.n_lists + list) * K;
+    // ---- merge the workgroup's WM*2 lists per query through LDS, write ONE list per query -------
+    {
+        constexpr int NL = WM * 2;  // lists per query inside this workgroup
+        static_assert(QROWS * NL * K * 8 <= NSTAGE * STAGE, "list merge scratch must fit in the ring");
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+        float *ls = (float *)smem;
+        int *lr = (int *)(smem + QROWS * NL * K * 4);
+        const int ql = wn * 32 + r32;
+        const int slot = (ql * NL + wm * 2 + h) * K;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            p.cand_s[base + i] = best.v[i];
-            p.cand_r[base + i] = best.r[i];
+            ls[slot + i] = best.v[i];
+            lr[slot + i] = best.r[i];
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < QROWS && q0 + t < p.B) {
+            TopList<K> m;
+            m.init();
+            for (int i = 0; i < NL * K; ++i) {
+                const float x = ls[t * NL * K + i];
+                const int xr = lr[t * NL * K + i];
+                if (xr != INT_MAX && better(x, xr, m.v[K - 1], m.r[K - 1])) m.insert_ordered(x, xr);
+            }
+            const size_t base = ((size_t)(q0 + t) * p.n_lists + blockIdx.x) * K;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                p.cand_s[base + i] = m.v[i];
+                p.cand_r[base + i] = m.r[i];
+            }
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -461,7 +498,7 @@ Plan make_plan(int B, long long n, int k) {
     pl.grid_x = pl.n_tiles < cus ? pl.n_tiles : cus;
     if (pl.grid_x < 1) pl.grid_x = 1;
     pl.NW = (pl.K == 5 && pl.WN == 8 && !getenv("MMRAG_NW8")) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
-    pl.n_lists = pl.grid_x * (pl.NW / pl.WN) * 2;
+    pl.n_lists = pl.grid_x;  // one merged list per workgroup per query
     pl.b_pad = pl.grid_y * qrows;
     return pl;
 }
