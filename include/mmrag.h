@@ -142,6 +142,7 @@ typedef struct mmrag_encoder_desc {
     int32_t pool, act, causal, normalize;
     int32_t out_dim; /* == hidden for BERT; projection width for MMRAG_ARCH_PRELN */
     float ln_eps;
+    int32_t image, patch; /* vision tower only (mmrag_vit_forward): square image side, patch side */
 } mmrag_encoder_desc;
 
 /* Weight table `w` (device pointers; matrices fp16 stored [out_features][in_features], i.e.
@@ -163,6 +164,21 @@ int mmrag_encoder_forward(const mmrag_encoder_desc *desc, const void *const *w, 
                           const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel,
                           int64_t T, int B, int max_len, float *out, void *workspace,
                           size_t workspace_bytes, void *stream);
+
+/* Vision tower (CLIP ViT-B/32 shape; BASELINE config 4 -- no reference behaviour):
+ * patchify (+ fused uint8 -> normalised fp16 preprocessing) -> patch-embedding GEMM -> class token +
+ * positions -> pre-LN -> the same pre-LN blocks / final LN / projection / L2 normalise as the text tower.
+ * Weight table: w[0] patch kernel [H, 3*P*P] (conv weight flattened), w[1] pos_emb [NP+1, H],
+ * w[2] class_embedding [H], w[3], w[4] pre-LN gamma/beta, layers and tail as for MMRAG_ARCH_PRELN.
+ *   pixels       dev: fp16 [B,3,image,image] already normalised (MMRAG_PIXELS_F16_CHW) or uint8
+ *                [B,image,image,3] raw crops (MMRAG_PIXELS_U8_HWC; CLIP mean/std applied on the GPU)
+ *   cu_seqlens   dev [B+1] int32 = b * (NP+1)
+ *   workspace    >= mmrag_encoder_workspace_bytes(desc, B*(NP+1), B) */
+#define MMRAG_PIXELS_F16_CHW 0
+#define MMRAG_PIXELS_U8_HWC 1
+int mmrag_vit_forward(const mmrag_encoder_desc *desc, const void *const *w, const void *pixels, int pixel_kind,
+                      const int32_t *cu_seqlens, int B, float *out, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* The encoder's building blocks, exported so each kernel can be parity-tested on its own. */
 int mmrag_linear_f16(const void *x, int64_t M, int K, const void *wt, int N, const float *bias, int act,

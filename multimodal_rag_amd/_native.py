@@ -62,6 +62,9 @@ def _declare(lib):
     lib.mmrag_encoder_forward.restype = c_int
     lib.mmrag_encoder_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_vit_forward.restype = c_int
+    lib.mmrag_vit_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]
     lib.mmrag_linear_f16.restype = c_int
     lib.mmrag_linear_f16.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p]
@@ -274,7 +277,7 @@ class EncoderDesc(ctypes.Structure):
     _fields_ = [("arch", c_int32), ("n_layers", c_int32), ("hidden", c_int32), ("n_heads", c_int32),
                 ("intermediate", c_int32), ("vocab", c_int32), ("max_pos", c_int32), ("pool", c_int32),
                 ("act", c_int32), ("causal", c_int32), ("normalize", c_int32), ("out_dim", c_int32),
-                ("ln_eps", c_float)]
+                ("ln_eps", c_float), ("image", c_int32), ("patch", c_int32)]
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -367,4 +370,26 @@ def encoder_forward(desc: EncoderDesc, weight_ptrs, ids: torch.Tensor, pos_ids: 
                                          workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                          _stream_ptr(ids.device))
     _check(st, "mmrag_encoder_forward")
+    return out
+
+
+PIXELS_F16_CHW, PIXELS_U8_HWC = 0, 1
+
+
+def vit_forward(desc: EncoderDesc, weight_ptrs, pixels: torch.Tensor, pixel_kind: int, cu_seqlens: torch.Tensor,
+                workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CLIP-style vision tower: images -> [B, out_dim] float32 L2-normalised."""
+    _dev_check(pixels, cu_seqlens, workspace, out)
+    B = pixels.shape[0]
+    S = (desc.image // desc.patch) ** 2 + 1
+    need = encoder_workspace_bytes(desc, B * S, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=pixels.device)
+    if out is None:
+        out = torch.empty((B, desc.out_dim), dtype=torch.float32, device=pixels.device)
+    with torch.cuda.device(pixels.device):
+        st = lib().mmrag_vit_forward(ctypes.byref(desc), weight_ptrs, pixels.data_ptr(), pixel_kind,
+                                     cu_seqlens.data_ptr(), B, out.data_ptr(), workspace.data_ptr(),
+                                     workspace.numel() * workspace.element_size(), _stream_ptr(pixels.device))
+    _check(st, "mmrag_vit_forward")
     return out

@@ -100,4 +100,31 @@ def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_b
                                "sample": f"oracle/encoder_oracle.py (numpy fp32) on {n_cpu} chunks x {SEQ} tokens"}
         res["parity_vs_oracle"] = bool(np.abs(got - ref).max() <= 4e-3 and (got * ref).sum(1).min() >= 0.9999)
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+    try:
+        res["clip_vit_b32"] = bench_clip_images(dev)
+    except Exception as e:  # the headline numbers must survive a failure of the extra leg
+        res["clip_vit_b32"] = {"error": str(e)}
     return res
+
+
+def bench_clip_images(dev, n_images: int = 256, steps: int = 5):
+    """Extra (BASELINE config 4): CLIP ViT-B/32 vision tower, uint8 224x224 tiles -> 512-d, images/s."""
+    from .clip import VIT_B32, DeviceClip
+
+    clip = DeviceClip.random_init(VIT_B32, seed=7, device=dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    tiles = torch.randint(0, 256, (n_images, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)
+    out = torch.empty((n_images, VIT_B32.proj), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        clip.encode_images(tiles, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        clip.encode_images(tiles, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    tf = n_images * clip.image_flops() / (ms * 1e-3) / 1e12
+    return {"images_per_s": round(n_images / ms * 1e3, 1), "ms_per_step": round(ms, 3), "images_per_step": n_images,
+            "tflops": round(tf, 1), "note": "vision tower incl. fused uint8 preprocessing, random-init fp16"}

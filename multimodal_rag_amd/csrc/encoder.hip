@@ -554,6 +554,51 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const _Float16 *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ViT front end.  patchify: image -> rows of the patch-embedding GEMM, vector order (c, ph, pw) =
+// the conv kernel's order.  Input either fp16 CHW already normalised, or raw uint8 HWC crops, in
+// which case CLIP's (x/255 - mean)/std normalisation is fused here (image preprocessing on the GPU).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const void *__restrict__ pixels, int kind,
+                                                        _Float16 *__restrict__ patches, int B, int IMG, int P) {
+    const int G = IMG / P, NP = G * G, PK = 3 * P * P, CH = PK / 8;
+    const long long total = (long long)B * NP * CH;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % CH);
+    const long long prow = i / CH;
+    const int pidx = (int)(prow % NP), b = (int)(prow / NP);
+    const int e0 = ch * 8;  // element offset inside the patch vector: 8 consecutive pw of one (c, ph)
+    const int c = e0 / (P * P), ph = (e0 / P) % P, pw = e0 % P;
+    const int y = (pidx / G) * P + ph, x0 = (pidx % G) * P + pw;
+    half8_t o;
+    if (kind == MMRAG_PIXELS_F16_CHW) {
+        o = *(const half8_t *)((const _Float16 *)pixels + (((size_t)b * 3 + c) * IMG + y) * IMG + x0);
+    } else {
+        const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+        const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+        const unsigned char *src = (const unsigned char *)pixels + (((size_t)b * IMG + y) * IMG + x0) * 3 + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)(((float)src[e * 3] / 255.0f - mean[c]) / stdv[c]);
+    }
+    *(half8_t *)(patches + (size_t)prow * PK + e0) = o;
+}
+
+// x[b*S + t] = LN_pre((t == 0 ? class_embedding : patch_emb[b*(S-1) + t-1]) + pos[t])
+__global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const _Float16 *__restrict__ emb,
+                                                               const _Float16 *__restrict__ cls,
+                                                               const _Float16 *__restrict__ pos,
+                                                               const float *__restrict__ g, const float *__restrict__ b,
+                                                               _Float16 *__restrict__ out, int T, int H, int S,
+                                                               float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int t = row % S, img = row / S;
+    const _Float16 *src = t == 0 ? cls : emb + ((size_t)img * (S - 1) + (t - 1)) * H;
+    ln_row<2>(src, out + (size_t)row * H, g, b, H, eps, lane, pos + (size_t)t * H);
+}
+
 // out[b, :] = x[b, :] / max(||x[b, :]||, 1e-12)  (fp16 in, fp32 out), one wave per row
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const _Float16 *__restrict__ x, float *__restrict__ out,
                                                               int B, int D) {
@@ -673,6 +718,16 @@ int mmrag_pool_normalize_f16(const void *x, const int32_t *cu_seqlens, const int
 // ---------------------------------------------------------------------------------------------
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+static size_t hm_elems(const mmrag_encoder_desc *d, int64_t T, int B) {
+    size_t n = (size_t)T * (size_t)d->intermediate;
+    if (d->patch > 0 && d->image > 0) {
+        const size_t g = (size_t)(d->image / d->patch);
+        const size_t patches = (size_t)B * g * g * 3 * (size_t)d->patch * (size_t)d->patch;
+        if (patches > n) n = patches;
+    }
+    return n;
+}
+
 size_t mmrag_encoder_workspace_bytes(const mmrag_encoder_desc *d, int64_t T, int B) {
     if (!d || T <= 0 || B <= 0) return 0;
     const size_t H = (size_t)d->hidden, I = (size_t)d->intermediate;
@@ -680,40 +735,41 @@ size_t mmrag_encoder_workspace_bytes(const mmrag_encoder_desc *d, int64_t T, int
     bytes += 2 * align256((size_t)T * H * 2);      // x, y
     bytes += align256((size_t)T * 3 * H * 2);      // qkv
     bytes += align256((size_t)T * H * 2);          // ctx
-    bytes += align256((size_t)T * I * 2);          // mlp hidden
+    bytes += align256(hm_elems(d, T, B) * 2);      // mlp hidden (also holds the ViT patch rows)
     bytes += 2 * align256((size_t)B * (H > (size_t)d->out_dim ? H : (size_t)d->out_dim) * 2);  // pooled, projected
     return bytes + 256;
 }
 
-int mmrag_encoder_forward(const mmrag_encoder_desc *d, const void *const *w, const int32_t *ids,
-                          const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel, int64_t T, int B,
-                          int max_len, float *out, void *workspace, size_t workspace_bytes, void *stream) {
-    MMRAG_CHECK_ARG(d && w && ids && pos_ids && cu_seqlens && out, "encoder_forward: null pointer");
-    MMRAG_CHECK_ARG(d->arch == MMRAG_ARCH_BERT || d->arch == MMRAG_ARCH_PRELN, "encoder_forward: bad arch %d", d->arch);
-    MMRAG_CHECK_ARG(T > 0 && T < INT_MAX && B > 0 && max_len > 0, "encoder_forward: bad shape T=%lld B=%d", (long long)T, B);
-    MMRAG_CHECK_ARG(d->hidden % 64 == 0 && d->intermediate % 64 == 0 && d->hidden <= 1024,
-                    "encoder_forward: hidden/intermediate must be multiples of 64 (hidden <= 1024)");
-    MMRAG_CHECK_ARG(d->pool >= 0 && d->pool <= 2 && (d->pool != 2 || sel), "encoder_forward: bad pool mode");
+struct EncBuffers {
+    void *x, *y, *qkv, *ctx, *hm, *pooled, *proj;
+};
+
+static int carve(const mmrag_encoder_desc *d, int64_t T, int B, void *workspace, size_t workspace_bytes,
+                 EncBuffers *b) {
     const size_t need = mmrag_encoder_workspace_bytes(d, T, B);
     if (!workspace || workspace_bytes < need) {
         set_error("encoder_forward: workspace %zu bytes < required %zu", workspace_bytes, need);
         return MMRAG_EWORKSPACE;
     }
-    const int H = d->hidden, I = d->intermediate, L = d->n_layers;
-    const size_t Tz = (size_t)T;
+    const size_t H = (size_t)d->hidden, Tz = (size_t)T;
     char *p = (char *)(((uintptr_t)workspace + 255) / 256 * 256);
     auto take = [&](size_t bytes) { char *r = p; p += align256(bytes); return (void *)r; };
-    void *x = take(Tz * H * 2), *y = take(Tz * H * 2), *qkv = take(Tz * 3 * H * 2), *ctx = take(Tz * H * 2);
-    void *hm = take(Tz * I * 2);
-    const size_t pd = (size_t)(H > d->out_dim ? H : d->out_dim);
-    void *pooled = take((size_t)B * pd * 2), *proj = take((size_t)B * pd * 2);
+    b->x = take(Tz * H * 2), b->y = take(Tz * H * 2), b->qkv = take(Tz * 3 * H * 2), b->ctx = take(Tz * H * 2);
+    b->hm = take(hm_elems(d, T, B) * 2);
+    const size_t pd = (size_t)(d->hidden > d->out_dim ? d->hidden : d->out_dim);
+    b->pooled = take((size_t)B * pd * 2), b->proj = take((size_t)B * pd * 2);
+    return MMRAG_OK;
+}
 
-    int st;
 #define RUN(call) do { if ((st = (call)) != MMRAG_OK) return st; } while (0)
-    // embeddings
-    RUN(mmrag_embed_ln_f16(ids, pos_ids, w[0], w[1], w[2], (const float *)w[3], (const float *)w[4], x, T, H,
-                           d->vocab, d->max_pos, d->ln_eps, stream));
-    const void *const *lw = w + 5;
+
+// transformer blocks + head over the packed activations already in b.x
+static int encoder_body(const mmrag_encoder_desc *d, const void *const *lw, const EncBuffers &b,
+                        const int32_t *cu_seqlens, const int32_t *sel, int64_t T, int B, int max_len, float *out,
+                        void *stream) {
+    const int H = d->hidden, I = d->intermediate, L = d->n_layers;
+    void *x = b.x, *y = b.y, *qkv = b.qkv, *ctx = b.ctx, *hm = b.hm;
+    int st;
     const int causal = d->causal;
     for (int l = 0; l < L; ++l, lw += 12) {
         const float *bqkv = (const float *)lw[1], *bo = (const float *)lw[3];
@@ -744,15 +800,69 @@ int mmrag_encoder_forward(const mmrag_encoder_desc *d, const void *const *w, con
     } else {
         // final LayerNorm (tail[0..1]), pooled token, bias-free projection (tail[2]), L2 normalise
         RUN(mmrag_layernorm_f16(x, y, (const float *)lw[0], (const float *)lw[1], T, H, d->ln_eps, stream));
-        pool_norm_kernel<_Float16><<<(unsigned)B, 256, 0, s>>>((const _Float16 *)y, cu_seqlens, sel, (_Float16 *)pooled, H,
-                                                               d->pool, 0);
+        pool_norm_kernel<_Float16><<<(unsigned)B, 256, 0, s>>>((const _Float16 *)y, cu_seqlens, sel,
+                                                               (_Float16 *)b.pooled, H, d->pool, 0);
         MMRAG_CHECK_HIP(hipGetLastError());
-        RUN(mmrag_linear_f16(pooled, B, H, lw[2], d->out_dim, nullptr, MMRAG_ACT_NONE, nullptr, proj, stream));
-        normalize_rows_kernel<<<(unsigned)((B + 3) / 4), 256, 0, s>>>((const _Float16 *)proj, out, B, d->out_dim);
+        RUN(mmrag_linear_f16(b.pooled, B, H, lw[2], d->out_dim, nullptr, MMRAG_ACT_NONE, nullptr, b.proj, stream));
+        normalize_rows_kernel<<<(unsigned)((B + 3) / 4), 256, 0, s>>>((const _Float16 *)b.proj, out, B, d->out_dim);
         MMRAG_CHECK_HIP(hipGetLastError());
     }
-#undef RUN
     return MMRAG_OK;
 }
+
+static int check_desc(const mmrag_encoder_desc *d) {
+    MMRAG_CHECK_ARG(d->arch == MMRAG_ARCH_BERT || d->arch == MMRAG_ARCH_PRELN, "encoder_forward: bad arch %d", d->arch);
+    MMRAG_CHECK_ARG(d->hidden % 64 == 0 && d->intermediate % 64 == 0 && d->hidden <= 1024,
+                    "encoder_forward: hidden/intermediate must be multiples of 64 (hidden <= 1024)");
+    MMRAG_CHECK_ARG(d->pool >= 0 && d->pool <= 2, "encoder_forward: bad pool mode");
+    return MMRAG_OK;
+}
+
+int mmrag_encoder_forward(const mmrag_encoder_desc *d, const void *const *w, const int32_t *ids,
+                          const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel, int64_t T, int B,
+                          int max_len, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    MMRAG_CHECK_ARG(d && w && ids && pos_ids && cu_seqlens && out, "encoder_forward: null pointer");
+    MMRAG_CHECK_ARG(T > 0 && T < INT_MAX && B > 0 && max_len > 0, "encoder_forward: bad shape T=%lld B=%d", (long long)T, B);
+    int st;
+    RUN(check_desc(d));
+    MMRAG_CHECK_ARG(d->pool != 2 || sel, "encoder_forward: MMRAG_POOL_SELECT needs sel");
+    EncBuffers b;
+    RUN(carve(d, T, B, workspace, workspace_bytes, &b));
+    RUN(mmrag_embed_ln_f16(ids, pos_ids, w[0], w[1], w[2], (const float *)w[3], (const float *)w[4], b.x, T,
+                           d->hidden, d->vocab, d->max_pos, d->ln_eps, stream));
+    return encoder_body(d, w + 5, b, cu_seqlens, sel, T, B, max_len, out, stream);
+}
+
+int mmrag_vit_forward(const mmrag_encoder_desc *d, const void *const *w, const void *pixels, int pixel_kind,
+                      const int32_t *cu_seqlens, int B, float *out, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    MMRAG_CHECK_ARG(d && w && pixels && cu_seqlens && out, "vit_forward: null pointer");
+    MMRAG_CHECK_ARG(B > 0, "vit_forward: bad batch %d", B);
+    int st;
+    RUN(check_desc(d));
+    MMRAG_CHECK_ARG(d->arch == MMRAG_ARCH_PRELN && d->pool == MMRAG_POOL_FIRST, "vit_forward: needs a pre-LN CLS-pooled desc");
+    MMRAG_CHECK_ARG(d->patch > 0 && d->image > 0 && d->image % d->patch == 0 && d->patch % 8 == 0,
+                    "vit_forward: bad image/patch %d/%d", d->image, d->patch);
+    MMRAG_CHECK_ARG(pixel_kind == MMRAG_PIXELS_F16_CHW || pixel_kind == MMRAG_PIXELS_U8_HWC, "vit_forward: bad pixel kind");
+    const int G = d->image / d->patch, NP = G * G, S = NP + 1;
+    const int PK = 3 * d->patch * d->patch;
+    MMRAG_CHECK_ARG(PK % 64 == 0, "vit_forward: 3*patch*patch must be a multiple of 64");
+    const int64_t T = (int64_t)B * S;
+    EncBuffers b;
+    RUN(carve(d, T, B, workspace, workspace_bytes, &b));
+    hipStream_t s = (hipStream_t)stream;
+    // patches -> b.hm [B*NP, 3*P*P]; patch embeddings -> b.qkv [B*NP, H]
+    const long long chunks = (long long)B * NP * (PK / 8);
+    patchify_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, s>>>(pixels, pixel_kind, (_Float16 *)b.hm, B, d->image,
+                                                                      d->patch);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    RUN(mmrag_linear_f16(b.hm, (int64_t)B * NP, PK, w[0], d->hidden, nullptr, MMRAG_ACT_NONE, nullptr, b.qkv, stream));
+    vit_assemble_ln_kernel<<<(unsigned)((T + 3) / 4), 256, 0, s>>>(
+        (const _Float16 *)b.qkv, (const _Float16 *)w[2], (const _Float16 *)w[1], (const float *)w[3],
+        (const float *)w[4], (_Float16 *)b.x, (int)T, d->hidden, S, d->ln_eps);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return encoder_body(d, w + 5, b, cu_seqlens, nullptr, T, B, S, out, stream);
+}
+#undef RUN
 
 }  // extern "C"
