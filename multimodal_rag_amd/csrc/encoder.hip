@@ -435,30 +435,39 @@ __global__ __launch_bounds__(256, 1) void attention_kernel(const _Float16 *__res
                 s[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[b], 0, 0, 0);
             }
         }
-        // scale, mask, running max
+        // softmax in the log2 domain on RAW scores: p = exp2(s*c - m*c), c = scale*log2(e) > 0, so the
+        // running max is taken on raw scores; masking only on tiles that touch the sequence end or the
+        // causal diagonal (wave-uniform test)
         const int k0 = kt * KT;
+        const bool edge = (k0 + KT > len) || (causal && k0 + KT - 1 > q_tile0 + wave * 32);
+        if (edge) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int key = k0 + b * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    const bool ok = key < len && (!causal || key <= qi);
+                    s[b][j] = ok ? s[b][j] : NEG_INF_F;
+                }
+        }
         float m_tile = NEG_INF_F;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int key = k0 + b * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                const bool ok = key < len && (!causal || key <= qi);
-                const float v = ok ? s[b][j] * scale : NEG_INF_F;
-                s[b][j] = v;
-                m_tile = fmaxf(m_tile, v);
-            }
+            for (int j = 0; j < 16; j += 2) m_tile = fmaxf(m_tile, fmaxf(s[b][j], s[b][j + 1]));
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
         const float m_new = fmaxf(m_run, m_tile);
         const float m_use = m_new == NEG_INF_F ? 0.f : m_new;  // fully masked row (padding query)
-        const float alpha = __expf(m_run - m_use);
+        const float c2 = scale * 1.4426950408889634f;
+        const float mc = m_use * c2;
+        const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mc);
         float psum = 0.f;
         half8_t pf[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float pv = __expf(s[b][j] - m_use);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[b][j], c2, -mc));
                 psum += pv;
                 pf[b][j >> 3][j & 7] = (_Float16)pv;
             }
