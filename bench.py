@@ -65,6 +65,16 @@ def cpu_baseline(q_host: np.ndarray, corpus_host: np.ndarray, k: int):
     from oracle import search_oracle as O
 
     threads = torch.get_num_threads()
+    try:  # the sgemm runs in numpy's OpenBLAS pool: report ITS thread count
+        from threadpoolctl import threadpool_info
+
+        blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
+        np_blas = [i["num_threads"] for i in threadpool_info()
+                   if i.get("user_api") == "blas" and "numpy" in (i.get("filepath") or "") or "openblas" in (i.get("internal_api") or "")]
+        if np_blas or blas:
+            threads = max(np_blas or blas)
+    except Exception:
+        pass
     t0 = time.perf_counter()
     s, r = O.cosine_topk(q_host, corpus_host, k)
     t1 = time.perf_counter()
