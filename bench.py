@@ -133,22 +133,27 @@ def main():
 
     corpus = make_unit_rows(lo, hi, DIM, ld, dtype, dev, base_seed=1234)
     q = make_unit_rows(0, B, DIM, ld, dtype, dev, base_seed=987654)
-    ws = torch.empty(N.cosine_topk_workspace_bytes(B, n_local, k) + 16, dtype=torch.uint8, device=dev)
+    # two workspaces: batch i+1's corpus scan may run while batch i's candidate merge, all-gather and
+    # copy-out are still in flight on the side stream
+    ws = [torch.empty(N.cosine_topk_workspace_bytes(B, n_local, k) + 16, dtype=torch.uint8, device=dev)
+          for _ in range(2)]
     events = {}
 
-    def local_search(slot, out_s, out_r):
+    def local_scan(slot):       # phase 1: the fused GEMM + top-k kernel (the roofline kernel)
         ev = events.get(slot)
         if ev is not None:
             ev[0].record()
-        N.cosine_topk_lists(q, corpus, n_local, DIM, k, ws)
+        N.cosine_topk_lists(q, corpus, n_local, DIM, k, ws[slot & 1])
         if ev is not None:
             ev[1].record()
-        N.cosine_topk_select(B, n_local, k, lo, ws, out_s, out_r)
+
+    def local_finish(slot, out_s, out_r):   # phase 2: per-query merge of the candidate lists
+        N.cosine_topk_select(B, n_local, k, lo, ws[slot & 1], out_s, out_r)
 
     from multimodal_rag_amd.sharded import ShardedSearch
 
-    ss = ShardedSearch(B, k, world, rank, dev, local_search, merge=args.merge,
-                       collective_on_host=(args.dist_backend == "gloo"))
+    ss = ShardedSearch(B, k, world, rank, dev, local_finish, merge=args.merge,
+                       collective_on_host=(args.dist_backend == "gloo"), local_scan=local_scan)
     final = {}
 
     def run(steps):

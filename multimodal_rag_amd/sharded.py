@@ -36,9 +36,16 @@ class ShardedSearch:
     def __init__(self, batch: int, k: int, world: int, rank: int, device: torch.device,
                  local_search: Callable[[int, torch.Tensor, torch.Tensor], None],
                  group: Optional[dist.ProcessGroup] = None, merge: str = "host",
-                 collective_on_host: bool = False):
+                 collective_on_host: bool = False,
+                 local_scan: Optional[Callable[[int], None]] = None):
         """local_search(slot, out_scores [B,k] f32, out_rows [B,k] i64) must enqueue / perform this
-        rank's shard search with GLOBAL row ids (-1 / -inf padding)."""
+        rank's shard search with GLOBAL row ids (-1 / -inf padding).
+
+        Two-phase form (GPU): if `local_scan(slot)` is given it is the corpus scan (phase 1 of
+        mmrag_cosine_topk, into a per-slot workspace) and runs on the caller's stream, while
+        local_search(slot, ...) is then only the small finishing step (phase 2).  Everything after
+        the scan -- finish, all-gather, copy to the host -- runs on a side stream, so the next
+        batch's scan does not wait for it (slots alternate between two buffer sets)."""
         if merge not in ("host", "device"):
             raise ValueError("merge must be 'host' or 'device'")
         self.B, self.k, self.world, self.rank = batch, k, world, rank
@@ -46,21 +53,28 @@ class ShardedSearch:
         self.group = group
         self.merge = merge
         self.local_search = local_search
+        self.local_scan = local_scan
         # rehearsal mode (gloo on a one-GPU box): the all-gather runs on host copies
         self.collective_on_host = collective_on_host and world > 1
         on_gpu = self.device.type == "cuda"
         # ONE packed exchange buffer per rank: [rows B*k i64 | scores B*k f32 | pad] -> one all-gather per batch
         nb = batch * k
         self.block_bytes = _native.packed_block_bytes(batch, k)
-        self.loc = torch.empty(self.block_bytes, dtype=torch.uint8, device=self.device)
-        self.loc_r = self.loc[: nb * 8].view(torch.int64).view(batch, k)
-        self.loc_s = self.loc[nb * 8: nb * 12].view(torch.float32).view(batch, k)
-        self.all = (torch.empty(world * self.block_bytes, dtype=torch.uint8, device=self.device)
-                    if world > 1 else self.loc)
+        self.locs, self.loc_rs, self.loc_ss, self.alls = [], [], [], []
+        for _ in range(2):  # two buffer sets: batch i+1 may start while batch i is still in its tail
+            loc = torch.empty(self.block_bytes, dtype=torch.uint8, device=self.device)
+            self.locs.append(loc)
+            self.loc_rs.append(loc[: nb * 8].view(torch.int64).view(batch, k))
+            self.loc_ss.append(loc[nb * 8: nb * 12].view(torch.float32).view(batch, k))
+            self.alls.append(torch.empty(world * self.block_bytes, dtype=torch.uint8, device=self.device)
+                             if world > 1 else loc)
         mk = (lambda: torch.empty(world * self.block_bytes, dtype=torch.uint8).pin_memory()) if on_gpu else (
             lambda: torch.empty(world * self.block_bytes, dtype=torch.uint8))
         self.host = [mk() for _ in range(2)]
         self.copied = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
+        self.side = torch.cuda.Stream(self.device) if (on_gpu and local_scan is not None) else None
+        self.scanned = [torch.cuda.Event() for _ in range(2)] if self.side is not None else None
+        self.tail_done = [None, None]
 
     def _views(self, buf: torch.Tensor):
         """[G, B, k] score / row views of a packed exchange buffer (strided over the rank blocks)."""
@@ -71,21 +85,38 @@ class ShardedSearch:
 
     def launch(self, slot: int):
         """Device phase of one query batch: shard search, all-gather, async copy (or device merge)."""
-        self.local_search(slot, self.loc_s, self.loc_r)
+        b = slot & 1
+        if self.side is None:
+            self._tail(slot, b)
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self.tail_done[b] is not None:
+            main.wait_event(self.tail_done[b])   # the slot's workspace / buffers are free again
+        self.local_scan(slot)
+        self.scanned[b].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.scanned[b])
+            self._tail(slot, b)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.tail_done[b] = ev
+
+    def _tail(self, slot: int, b: int):
+        loc, all_ = self.locs[b], self.alls[b]
+        self.local_search(slot, self.loc_ss[b], self.loc_rs[b])
         if self.collective_on_host:
             gathered = torch.empty(self.world * self.block_bytes, dtype=torch.uint8)
-            dist.all_gather_into_tensor(gathered, self.loc.cpu(), group=self.group)
-            self.all.copy_(gathered)
+            dist.all_gather_into_tensor(gathered, loc.cpu(), group=self.group)
+            all_.copy_(gathered)
         elif self.world > 1:
-            dist.all_gather_into_tensor(self.all, self.loc, group=self.group)
-        b = slot & 1
+            dist.all_gather_into_tensor(all_, loc, group=self.group)
         if self.merge == "device" and self.world > 1:
-            s, r = _native.merge_topk(*self._views(self.all), self.k)
+            s, r = _native.merge_topk(*self._views(all_), self.k)
             nb = self.B * self.k
             self.host[b][nb * 8: nb * 12].view(torch.float32).view(self.B, self.k).copy_(s, non_blocking=True)
             self.host[b][: nb * 8].view(torch.int64).view(self.B, self.k).copy_(r, non_blocking=True)
         else:
-            self.host[b].copy_(self.all, non_blocking=True)
+            self.host[b].copy_(all_, non_blocking=True)
         if self.copied is not None:
             self.copied[b].record()
 
