@@ -1,7 +1,4 @@
-"""A/B the linear kernel configs in ONE process (MMRAG_LINEAR_CFG is read once per process, so
-each config runs in a child... no: read per call here via re-exec is not possible; the C side
-caches it, so this script is started once per config by the shell and prints comparable numbers
-against a fixed reference config measured in the same process: torch.matmul (rocBLAS)."""
+"""Developer check: mmrag_linear_f16 vs torch.matmul (hipBLASLt) on the encoder GEMM shapes, one process."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,4 +17,4 @@ for K, Nf in [(768, 2304), (768, 768), (768, 3072), (3072, 768)]:
     fl = 2.0 * M * K * Nf
     mine = sorted(t(lambda: N.linear_f16(x, w, b, 0, None, out)) for _ in range(3))[1]
     ref = sorted(t(lambda: torch.matmul(x, w.t())) for _ in range(3))[1]
-    print(f"cfg={os.environ.get('MMRAG_LINEAR_CFG','0')} K={K} N={Nf}: mine {mine:.1f} us {fl/mine/1e6:.0f} TF | rocBLAS {ref:.1f} us {fl/ref/1e6:.0f} TF", flush=True)
+    print(f"K={K} N={Nf}: mine {mine:.1f} us {fl/mine/1e6:.0f} TF | rocBLAS {ref:.1f} us {fl/ref/1e6:.0f} TF", flush=True)
