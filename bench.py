@@ -139,16 +139,19 @@ def main():
           for _ in range(2)]
     events = {}
 
+    plans = [N.SearchPlan(q, corpus, n_local, DIM, k, ws[i]) for i in range(2)]
+    main_stream = torch.cuda.current_stream(dev).cuda_stream
+
     def local_scan(slot):       # phase 1: the fused GEMM + top-k kernel (the roofline kernel)
         ev = events.get(slot)
         if ev is not None:
             ev[0].record()
-        N.cosine_topk_lists(q, corpus, n_local, DIM, k, ws[slot & 1])
+        plans[slot & 1].scan(main_stream)
         if ev is not None:
             ev[1].record()
 
-    def local_finish(slot, out_s, out_r):   # phase 2: per-query merge of the candidate lists
-        N.cosine_topk_select(B, n_local, k, lo, ws[slot & 1], out_s, out_r)
+    def local_finish(slot, out_s, out_r):   # phase 2: per-query merge of the candidate lists (side stream)
+        plans[slot & 1].select(lo, out_s.data_ptr(), out_r.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
 
     from multimodal_rag_amd.sharded import ShardedSearch
 

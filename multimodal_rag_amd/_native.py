@@ -393,3 +393,39 @@ def vit_forward(desc: EncoderDesc, weight_ptrs, pixels: torch.Tensor, pixel_kind
                                      workspace.numel() * workspace.element_size(), _stream_ptr(pixels.device))
     _check(st, "mmrag_vit_forward")
     return out
+
+
+class SearchPlan:
+    """Pre-validated, pointer-cached form of cosine_topk_lists / cosine_topk_select for hot loops
+    (a serving loop or bench.py issues the same shapes thousands of times; argument checking and
+    torch context managers would otherwise dominate the host time per batch at small shard sizes).
+    The tensors are kept alive by the plan; `stream` arguments are raw hipStream_t values."""
+
+    def __init__(self, q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, workspace: torch.Tensor,
+                 alive_bits: Optional[torch.Tensor] = None):
+        _dev_check(q, corpus, workspace, alive_bits)
+        if q.dtype != corpus.dtype or q.shape[1] != corpus.shape[1] or not q.is_contiguous() or not corpus.is_contiguous():
+            raise MMRagNativeError("SearchPlan: q and corpus must be contiguous and share dtype and padded width")
+        if n > corpus.shape[0]:
+            raise MMRagNativeError(f"SearchPlan: n={n} exceeds corpus capacity {corpus.shape[0]}")
+        need = lib().mmrag_cosine_topk_workspace_bytes(q.shape[0], n, k)
+        if workspace.numel() * workspace.element_size() < need:
+            raise MMRagNativeError("SearchPlan: workspace too small")
+        self._keep = (q, corpus, workspace, alive_bits)
+        self.B, self.n, self.k = q.shape[0], n, k
+        self._scan_args = (q.data_ptr(), corpus.data_ptr(), q.shape[0], n, d, q.shape[1], _TORCH2DT[q.dtype], k,
+                           alive_bits.data_ptr() if alive_bits is not None else None, workspace.data_ptr(),
+                           workspace.numel() * workspace.element_size())
+        self._ws = workspace.data_ptr()
+        self._scan = lib().mmrag_cosine_topk_lists
+        self._select = lib().mmrag_cosine_topk_select
+
+    def scan(self, stream: int) -> None:
+        st = self._scan(*self._scan_args, stream)
+        if st:
+            _check(st, "mmrag_cosine_topk_lists")
+
+    def select(self, row_offset: int, out_scores_ptr: int, out_rows_ptr: int, stream: int) -> None:
+        st = self._select(self.B, self.n, self.k, row_offset, self._ws, out_scores_ptr, out_rows_ptr, stream)
+        if st:
+            _check(st, "mmrag_cosine_topk_select")

@@ -74,7 +74,8 @@ class ShardedSearch:
         self.copied = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
         self.side = torch.cuda.Stream(self.device) if (on_gpu and local_scan is not None) else None
         self.scanned = [torch.cuda.Event() for _ in range(2)] if self.side is not None else None
-        self.tail_done = [None, None]
+        self.tail_done = [torch.cuda.Event() for _ in range(2)] if self.side is not None else None
+        self._tail_used = [False, False]
 
     def _views(self, buf: torch.Tensor):
         """[G, B, k] score / row views of a packed exchange buffer (strided over the rank blocks)."""
@@ -90,16 +91,15 @@ class ShardedSearch:
             self._tail(slot, b)
             return
         main = torch.cuda.current_stream(self.device)
-        if self.tail_done[b] is not None:
+        if self._tail_used[b]:
             main.wait_event(self.tail_done[b])   # the slot's workspace / buffers are free again
         self.local_scan(slot)
         self.scanned[b].record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.scanned[b])
             self._tail(slot, b)
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            self.tail_done[b] = ev
+            self.tail_done[b].record(self.side)
+            self._tail_used[b] = True
 
     def _tail(self, slot: int, b: int):
         loc, all_ = self.locs[b], self.alls[b]
