@@ -125,7 +125,9 @@ struct KParams {
     int B;
     unsigned row_bytes;   // ld * esize, multiple of 128
     int n_tiles;
-    int n_lists;          // gridDim.x (lists are merged per workgroup before they are written)
+    int n_lists;          // list slots per query in cand_* (>= gridDim.x)
+    int tile0;            // first corpus tile of this launch (sample pre-pass / main pass split)
+    const float *thr0;    // optional [B]: a known lower bound of each query's final k-th score
 };
 
 template <int DT, int WN, int K, int NSTAGE, int NW>
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
 
     int is_tile = 0, is_k = 0;  // issue cursor: (index among my tiles, k slab)
     auto issue = [&](int stage_idx) {
-        const long long tile = (long long)blockIdx.x + (long long)is_tile * gridDim.x;
+        const long long tile = (long long)p.tile0 + blockIdx.x + (long long)is_tile * gridDim.x;
         const long long row0 = tile * TM;
         const long long rows_left = p.n - row0;
         const unsigned c_bytes = (unsigned)((rows_left < TM ? rows_left : (long long)TM) * (long long)RB);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
     // ---- accumulators, lists ---------------------------------------------------------------
     f32x16_t acc[RM];
     auto init_acc = [&](int tile_idx) {
-        const long long tile = (long long)blockIdx.x + (long long)tile_idx * gridDim.x;
+        const long long tile = (long long)p.tile0 + blockIdx.x + (long long)tile_idx * gridDim.x;
         const long long row0 = tile * TM + (long long)wm * (RM * 32);
         const bool ragged = row0 + RM * 32 > p.n;
         if (!ragged && p.alive_bits == nullptr) {
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
     TopList<K> best;
     best.init();
     float thr = NEG_INF;
+    if (p.thr0 != nullptr && q0 + wn * 32 + r32 < p.B) thr = p.thr0[q0 + wn * 32 + r32];
 
     // ---- fragment addresses (bytes inside a stage) ------------------------------------------
     const int sw = (r32 >> 1) & 7;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
         if (++ks == nk) {
             // ---- epilogue: lane-local top-K over this wave's 32*RM rows of the tile ----------
             ks = 0;
-            const long long tile = (long long)blockIdx.x + (long long)tile_idx * gridDim.x;
+            const long long tile = (long long)p.tile0 + blockIdx.x + (long long)tile_idx * gridDim.x;
             const int row_base = (int)(tile * TM) + wm * (RM * 32) + 4 * h;
 #pragma unroll
             for (int b = 0; b < RM; ++b) {
@@ -484,6 +487,7 @@ struct Plan {
     int n_tiles;
     int n_lists;
     int b_pad;
+    int pre_tiles;  // > 0: a sample pre-pass over the first pre_tiles tiles seeds the selection thresholds
 };
 
 Plan make_plan(int B, long long n, int k) {
@@ -500,7 +504,12 @@ Plan make_plan(int B, long long n, int k) {
     pl.grid_x = pl.n_tiles < cus ? pl.n_tiles : cus;
     if (pl.grid_x < 1) pl.grid_x = 1;
     pl.NW = (pl.K == 5 && pl.WN == 8 && !getenv("MMRAG_NW8")) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
-    pl.n_lists = pl.grid_x;  // one merged list per workgroup per query
+    // Sample pre-pass (256-query shape only: there the epilogue, not HBM, is what thresholds relieve).
+    // The exact top-K of the first `cus` tiles gives every query a threshold as tight as if each
+    // workgroup had already seen 65k rows, so the main pass almost never takes the insertion path.
+    pl.pre_tiles = 0;
+    if (pl.K == 5 && pl.WN == 8 && pl.n_tiles >= 3 * cus && !getenv("MMRAG_NO_PREPASS")) pl.pre_tiles = cus;
+    pl.n_lists = pl.grid_x + (pl.pre_tiles ? 1 : 0);  // one merged list per workgroup per query (+ the sample's)
     pl.b_pad = pl.grid_y * qrows;
     return pl;
 }
@@ -542,6 +551,24 @@ int launch_merge(int K, const float *cs, const RowT *cr, long long n_cand, long 
     return MMRAG_OK;
 }
 
+// after the sample pre-pass: thr0[q] = k-th score of the sample's exact top-K (a valid lower bound of
+// the final k-th score), and the sample's top-K becomes one more candidate list of the final merge
+template <int K>
+__global__ void seed_kernel(const float *__restrict__ top_s, const long long *__restrict__ top_r, int B,
+                            float *__restrict__ thr0, float *__restrict__ cand_s, int *__restrict__ cand_r,
+                            int n_lists, int slot) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B) return;
+    thr0[q] = top_s[(size_t)q * K + K - 1];  // -inf when the sample held fewer than K live rows
+    const size_t base = ((size_t)q * n_lists + slot) * K;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const long long r = top_r[(size_t)q * K + i];
+        cand_s[base + i] = top_s[(size_t)q * K + i];
+        cand_r[base + i] = r < 0 ? INT_MAX : (int)r;
+    }
+}
+
 __global__ void fill_empty_kernel(float *s, long long *r, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
@@ -555,11 +582,24 @@ using namespace mmrag_impl;
 
 extern "C" {
 
+// workspace: [cand_s entries f32][cand_r entries i32][thr0 b_pad f32][sample top_s b_pad*K f32][pad][sample top_r b_pad*K i64]
+struct WsLayout {
+    size_t entries, off_r, off_thr, off_ts, off_tr, total;
+};
+static WsLayout ws_layout(const Plan &pl) {
+    WsLayout w;
+    w.entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
+    w.off_r = w.entries * sizeof(float);
+    w.off_thr = w.off_r + w.entries * sizeof(int);
+    w.off_ts = w.off_thr + (size_t)pl.b_pad * sizeof(float);
+    w.off_tr = (w.off_ts + (size_t)pl.b_pad * pl.K * sizeof(float) + 15) / 16 * 16;
+    w.total = w.off_tr + (size_t)pl.b_pad * pl.K * sizeof(long long);
+    return w;
+}
+
 size_t mmrag_cosine_topk_workspace_bytes(int B, int64_t n, int k) {
     if (B <= 0 || n < 0 || k < 1 || k > MMRAG_MAX_K) return 0;
-    const Plan pl = make_plan(B, n, k);
-    const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
-    return entries * (sizeof(float) + sizeof(int)) + 256;
+    return ws_layout(make_plan(B, n, k)).total + 256;
 }
 
 static int check_search_args(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
@@ -586,10 +626,9 @@ int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n,
     if (int st = check_search_args(q, corpus, B, n, d, ld, dtype, k)) return st;
     if (n == 0) return MMRAG_OK;
     const Plan pl = make_plan(B, n, k);
-    const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
-    const size_t need = entries * (sizeof(float) + sizeof(int));
-    if (!workspace || workspace_bytes < need) {
-        set_error("cosine_topk: workspace %zu bytes < required %zu", workspace_bytes, need);
+    const WsLayout wl = ws_layout(pl);
+    if (!workspace || workspace_bytes < wl.total) {
+        set_error("cosine_topk: workspace %zu bytes < required %zu", workspace_bytes, wl.total);
         return MMRAG_EWORKSPACE;
     }
     MMRAG_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "cosine_topk: workspace must be 16-byte aligned");
@@ -599,16 +638,50 @@ int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n,
     p.corpus = (const char *)corpus;
     p.alive_bits = alive_bits;
     p.cand_s = (float *)workspace;
-    p.cand_r = (int *)((char *)workspace + entries * sizeof(float));
+    p.cand_r = (int *)((char *)workspace + wl.off_r);
     p.n = n;
     p.B = B;
     p.row_bytes = (unsigned)(ld * esize(dtype));
     p.n_tiles = pl.n_tiles;
     p.n_lists = pl.n_lists;
+    p.tile0 = 0;
+    p.thr0 = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMRAG_F32) dispatch_main<MMRAG_F32>(pl, p, s);
-    else if (dtype == MMRAG_F16) dispatch_main<MMRAG_F16>(pl, p, s);
-    else dispatch_main<MMRAG_BF16>(pl, p, s);
+    auto run = [&](const Plan &lp, const KParams &kp) {
+        if (dtype == MMRAG_F32) dispatch_main<MMRAG_F32>(lp, kp, s);
+        else if (dtype == MMRAG_F16) dispatch_main<MMRAG_F16>(lp, kp, s);
+        else dispatch_main<MMRAG_BF16>(lp, kp, s);
+    };
+    if (pl.pre_tiles > 0) {
+        // 1. sample pre-pass over tiles [0, pre_tiles): one tile per workgroup
+        float *thr0 = (float *)((char *)workspace + wl.off_thr);
+        float *top_s = (float *)((char *)workspace + wl.off_ts);
+        long long *top_r = (long long *)((char *)workspace + wl.off_tr);
+        Plan pre = pl;
+        pre.n_tiles = pl.pre_tiles;
+        pre.grid_x = pl.pre_tiles < pl.grid_x ? pl.pre_tiles : pl.grid_x;
+        KParams kp = p;
+        kp.n_tiles = pre.n_tiles;
+        run(pre, kp);
+        MMRAG_CHECK_HIP(hipGetLastError());
+        // 2. its exact top-K per query, 3. seed thresholds + keep it as the last candidate list
+        const long long n_cand = (long long)pre.grid_x * pl.K;
+        launch_merge<int>(pl.K, p.cand_s, p.cand_r, n_cand, n_cand, 0, (long long)pl.n_lists * pl.K, B, pl.K, 0, top_s,
+                          top_r, s);
+        seed_kernel<5><<<(unsigned)((B + 255) / 256), 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r,
+                                                                   pl.n_lists, pl.n_lists - 1);
+        MMRAG_CHECK_HIP(hipGetLastError());
+        // 4. main pass over the remaining tiles, selection armed with the sample thresholds
+        Plan mainp = pl;
+        mainp.n_tiles = pl.n_tiles - pl.pre_tiles;
+        KParams km = p;
+        km.n_tiles = mainp.n_tiles;
+        km.tile0 = pl.pre_tiles;
+        km.thr0 = thr0;
+        run(mainp, km);
+    } else {
+        run(pl, p);
+    }
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;
 }
@@ -626,9 +699,9 @@ int mmrag_cosine_topk_select(int B, int64_t n, int k, int64_t row_offset, const 
     }
     MMRAG_CHECK_ARG(workspace, "cosine_topk_select: null workspace");
     const Plan pl = make_plan(B, n, k);
-    const size_t entries = (size_t)pl.b_pad * pl.n_lists * pl.K;
+    const WsLayout wl = ws_layout(pl);
     const float *cand_s = (const float *)workspace;
-    const int *cand_r = (const int *)((const char *)workspace + entries * sizeof(float));
+    const int *cand_r = (const int *)((const char *)workspace + wl.off_r);
     const long long n_cand = (long long)pl.n_lists * pl.K;
     launch_merge<int>(pl.K, cand_s, cand_r, n_cand, n_cand, 0, n_cand, B, k, row_offset, out_scores,
                       (long long *)out_rows, s);
