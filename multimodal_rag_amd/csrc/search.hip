@@ -130,7 +130,8 @@ struct KParams {
     const float *thr0;    // optional [B]: a known lower bound of each query's final k-th score
 };
 
-template <int DT, int WN, int K, int NSTAGE, int NW>
+
+template <int DT, int WN, int K, int NSTAGE, int NW, bool SEEDED>
 __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // amdgcn builtins below: the host pass only needs the launch stub
     constexpr int WM = NW / WN;          // waves along corpus rows
@@ -301,15 +302,38 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
             ks = 0;
             const long long tile = (long long)p.tile0 + blockIdx.x + (long long)tile_idx * gridDim.x;
             const int row_base = (int)(tile * TM) + wm * (RM * 32) + 4 * h;
+            if constexpr (SEEDED) {
+                // thresholds are warm from the first element (sample pre-pass): test 4 rows at a time
 #pragma unroll
-            for (int b = 0; b < RM; ++b) {
+                for (int b = 0; b < RM; ++b) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float s = acc[b][j];
-                    const bool pass = s >= thr;
-                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                        best.insert_strict(pass ? s : NEG_INF, row_base + b * 32 + (j & 3) + 8 * (j >> 2));
-                        thr = fmaxf(thr, best.v[K - 1]);
+                    for (int g = 0; g < 4; ++g) {
+                        const float m4 = fmaxf(fmaxf(acc[b][4 * g], acc[b][4 * g + 1]),
+                                               fmaxf(acc[b][4 * g + 2], acc[b][4 * g + 3]));
+                        if (__builtin_amdgcn_ballot_w64(m4 >= thr) != 0ull) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float s = acc[b][4 * g + i];
+                                const bool pass = s >= thr;
+                                if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                                    best.insert_strict(pass ? s : NEG_INF, row_base + b * 32 + i + 8 * g);
+                                    thr = fmaxf(thr, best.v[K - 1]);
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < RM; ++b) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float s = acc[b][j];
+                        const bool pass = s >= thr;
+                        if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                            best.insert_strict(pass ? s : NEG_INF, row_base + b * 32 + (j & 3) + 8 * (j >> 2));
+                            thr = fmaxf(thr, best.v[K - 1]);
+                        }
                     }
                 }
             }
@@ -514,9 +538,9 @@ Plan make_plan(int B, long long n, int k) {
     return pl;
 }
 
-template <int DT, int WN, int K, int NSTAGE, int NW = 8>
+template <int DT, int WN, int K, int NSTAGE, int NW = 8, bool SEEDED = false>
 void launch_main(const KParams &p, dim3 grid, hipStream_t s) {
-    cosine_topk_kernel<DT, WN, K, NSTAGE, NW><<<grid, 64 * NW, 0, s>>>(p);
+    cosine_topk_kernel<DT, WN, K, NSTAGE, NW, SEEDED><<<grid, 64 * NW, 0, s>>>(p);
 }
 
 template <int DT>
@@ -525,7 +549,9 @@ int dispatch_main(const Plan &pl, const KParams &p, hipStream_t s) {
     if (pl.K == 5) {
         if (pl.WN == 2) launch_main<DT, 2, 5, 3>(p, grid, s);
         else if (pl.WN == 4) launch_main<DT, 4, 5, 3>(p, grid, s);
+        else if (pl.NW == 16 && p.thr0) launch_main<DT, 8, 5, 2, 16, true>(p, grid, s);
         else if (pl.NW == 16) launch_main<DT, 8, 5, 2, 16>(p, grid, s);
+        else if (p.thr0) launch_main<DT, 8, 5, 2, 8, true>(p, grid, s);
         else launch_main<DT, 8, 5, 2>(p, grid, s);
     } else if (pl.K == 10) {
         launch_main<DT, 2, 10, 3>(p, grid, s);

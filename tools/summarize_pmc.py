@@ -12,12 +12,18 @@ import sys
 
 def main(fetch_csv, out_json, rows_per_gpu, batch, write_csv=None, kernel="cosine_topk_kernel"):
     def avg(path, counter):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+        # one scan launches each instantiation once (sample pre-pass + main pass): average per
+        # instantiation, then add them up -> bytes per scan
+        per = {}
+        for r in csv.DictReader(open(path)):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        if not per:
+            return None, 0
+        return sum(sum(v) / len(v) for v in per.values()), max(len(v) for v in per.values())
 
     f, nf = avg(fetch_csv, "FETCH_SIZE")
-    out = {"kernel": kernel, "rows_per_gpu": int(rows_per_gpu), "batch": int(batch), "launches": nf,
+    out = {"kernel": kernel, "rows_per_gpu": int(rows_per_gpu), "batch": int(batch), "scans": nf,
            "fetch_size_kib_raw": f, "hbm_read_bytes_per_launch": f * 1024 * 2,
            "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 counts 128-B requests at 64 B)"}
     total = out["hbm_read_bytes_per_launch"]
