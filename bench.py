@@ -114,8 +114,13 @@ def main():
 
     import torch.distributed as dist
 
-    if world > 1:
+    # MMRAG_BENCH_FORCE_EXCHANGE=1: run the RCCL all-gather + merge with a single rank (one-GPU rehearsal of
+    # the N > 1 path; launch through torch.distributed.run --nproc-per-node 1)
+    force_exchange = world == 1 and os.environ.get("MMRAG_BENCH_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")  # RCCL's stream: same reason as the side stream
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -133,43 +138,54 @@ def main():
 
     corpus = make_unit_rows(lo, hi, DIM, ld, dtype, dev, base_seed=1234)
     q = make_unit_rows(0, B, DIM, ld, dtype, dev, base_seed=987654)
-    # two workspaces: batch i+1's corpus scan may run while batch i's candidate merge, all-gather and
-    # copy-out are still in flight on the side stream
+    # SLOTS workspaces / buffer sets: later batches' corpus scans run while batch i's candidate merge,
+    # all-gather and copy-out are still in flight on the side stream.  A batch's scan + tail latency
+    # exceeds one host launch at small shards (125k rows: 87 + 40 us vs 60 us), hence more than two.
+    SLOTS = 4
     ws = [torch.empty(N.cosine_topk_workspace_bytes(B, n_local, k) + 16, dtype=torch.uint8, device=dev)
-          for _ in range(2)]
+          for _ in range(SLOTS)]
     events = {}
 
-    plans = [N.SearchPlan(q, corpus, n_local, DIM, k, ws[i]) for i in range(2)]
+    plans = [N.SearchPlan(q, corpus, n_local, DIM, k, ws[i]) for i in range(SLOTS)]
     main_stream = torch.cuda.current_stream(dev).cuda_stream
 
     def local_scan(slot):       # phase 1: the fused GEMM + top-k kernel (the roofline kernel)
         ev = events.get(slot)
         if ev is not None:
             ev[0].record()
-        plans[slot & 1].scan(main_stream)
+        plans[slot % SLOTS].scan(main_stream)
         if ev is not None:
             ev[1].record()
 
     def local_finish(slot, out_s, out_r):   # phase 2: per-query merge of the candidate lists (side stream)
-        plans[slot & 1].select(lo, out_s.data_ptr(), out_r.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        plans[slot % SLOTS].select(lo, out_s.data_ptr(), out_r.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
 
     from multimodal_rag_amd.sharded import ShardedSearch
 
     ss = ShardedSearch(B, k, world, rank, dev, local_finish, merge=args.merge,
-                       collective_on_host=(args.dist_backend == "gloo"), local_scan=local_scan)
+                       collective_on_host=(args.dist_backend == "gloo"), local_scan=local_scan,
+                       force_exchange=force_exchange, n_slots=SLOTS)
     final = {}
 
+    host_t = {"launch": 0.0, "finish": 0.0}
+    LAG = SLOTS - 1  # batches in flight behind the one whose results the host is merging
+
     def run(steps):
+        pc = time.perf_counter
         for i in range(steps):
+            t0 = pc()
             ss.launch(i)
-            if i > 0:
-                final["s"], final["r"] = ss.finish(i - 1)  # overlaps the device work of step i
-        if steps:
-            final["s"], final["r"] = ss.finish(steps - 1)
+            t1 = pc()
+            if i >= LAG:
+                final["s"], final["r"] = ss.finish(i - LAG)  # overlaps the device work of steps i-LAG+1 .. i
+            host_t["launch"] += t1 - t0
+            host_t["finish"] += pc() - t1
+        for j in range(max(0, steps - LAG), steps):
+            final["s"], final["r"] = ss.finish(j)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_exchange:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -178,10 +194,13 @@ def main():
         events[i] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     sync_all()
     t0 = time.perf_counter()
+    host_t["launch"] = host_t["finish"] = 0.0
     run(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    log(f"[rank {rank}] host time per step: launch {host_t['launch'] / args.steps * 1e6:.1f} us, "
+        f"finish (wait + merge) {host_t['finish'] / args.steps * 1e6:.1f} us")
+    if world > 1 or force_exchange:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -266,7 +285,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

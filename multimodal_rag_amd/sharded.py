@@ -13,8 +13,9 @@ The reference is single-process (no collective anywhere),
 replaces reference code; it is the exchange step the row-sharded index needs.
 
 `launch()` enqueues the device work of one query batch and returns immediately; `finish()`
-waits for that batch's copy and merges on the host, so callers can overlap batch i+1's device
-work with batch i's merge (two buffers).
+waits for that batch's copy and merges on the host, so callers can keep `n_slots - 1` batches
+in flight behind the one being merged (`n_slots` buffer sets; a batch's scan + tail latency is
+longer than one host launch at small shards, so two sets leave the host waiting).
 """
 from __future__ import annotations
 
@@ -37,7 +38,8 @@ class ShardedSearch:
                  local_search: Callable[[int, torch.Tensor, torch.Tensor], None],
                  group: Optional[dist.ProcessGroup] = None, merge: str = "host",
                  collective_on_host: bool = False,
-                 local_scan: Optional[Callable[[int], None]] = None):
+                 local_scan: Optional[Callable[[int], None]] = None, force_exchange: bool = False,
+                 n_slots: int = 2):
         """local_search(slot, out_scores [B,k] f32, out_rows [B,k] i64) must enqueue / perform this
         rank's shard search with GLOBAL row ids (-1 / -inf padding).
 
@@ -45,9 +47,15 @@ class ShardedSearch:
         mmrag_cosine_topk, into a per-slot workspace) and runs on the caller's stream, while
         local_search(slot, ...) is then only the small finishing step (phase 2).  Everything after
         the scan -- finish, all-gather, copy to the host -- runs on a side stream, so the next
-        batch's scan does not wait for it (slots alternate between two buffer sets)."""
+        batch's scan does not wait for it (slots alternate between two buffer sets).
+
+        force_exchange: run the all-gather and the G*k -> k merge even when world == 1 (rehearses the
+        RCCL path on a one-GPU box; needs an initialised process group)."""
         if merge not in ("host", "device"):
             raise ValueError("merge must be 'host' or 'device'")
+        if n_slots < 1:
+            raise ValueError("n_slots must be >= 1")
+        self.n_slots = n_slots
         self.B, self.k, self.world, self.rank = batch, k, world, rank
         self.device = torch.device(device)
         self.group = group
@@ -55,27 +63,31 @@ class ShardedSearch:
         self.local_search = local_search
         self.local_scan = local_scan
         # rehearsal mode (gloo on a one-GPU box): the all-gather runs on host copies
-        self.collective_on_host = collective_on_host and world > 1
+        self.exchange = world > 1 or force_exchange
+        self.collective_on_host = collective_on_host and self.exchange
         on_gpu = self.device.type == "cuda"
         # ONE packed exchange buffer per rank: [rows B*k i64 | scores B*k f32 | pad] -> one all-gather per batch
         nb = batch * k
         self.block_bytes = _native.packed_block_bytes(batch, k)
         self.locs, self.loc_rs, self.loc_ss, self.alls = [], [], [], []
-        for _ in range(2):  # two buffer sets: batch i+1 may start while batch i is still in its tail
+        for _ in range(n_slots):  # buffer sets: later batches may start while batch i is still in its tail
             loc = torch.empty(self.block_bytes, dtype=torch.uint8, device=self.device)
             self.locs.append(loc)
             self.loc_rs.append(loc[: nb * 8].view(torch.int64).view(batch, k))
             self.loc_ss.append(loc[nb * 8: nb * 12].view(torch.float32).view(batch, k))
             self.alls.append(torch.empty(world * self.block_bytes, dtype=torch.uint8, device=self.device)
-                             if world > 1 else loc)
+                             if self.exchange else loc)
         mk = (lambda: torch.empty(world * self.block_bytes, dtype=torch.uint8).pin_memory()) if on_gpu else (
             lambda: torch.empty(world * self.block_bytes, dtype=torch.uint8))
-        self.host = [mk() for _ in range(2)]
-        self.copied = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
-        self.side = torch.cuda.Stream(self.device) if (on_gpu and local_scan is not None) else None
-        self.scanned = [torch.cuda.Event() for _ in range(2)] if self.side is not None else None
-        self.tail_done = [torch.cuda.Event() for _ in range(2)] if self.side is not None else None
-        self._tail_used = [False, False]
+        self.host = [mk() for _ in range(n_slots)]
+        self.copied = [torch.cuda.Event() for _ in range(n_slots)] if on_gpu else None
+        # High priority: the persistent scan kernel fills every CU, so tail kernels only get CUs as scan
+        # workgroups retire; at equal priority the next batch's scan is dispatched first and each tail op
+        # waits out a whole scan.
+        self.side = torch.cuda.Stream(self.device, priority=-1) if (on_gpu and local_scan is not None) else None
+        self.scanned = [torch.cuda.Event() for _ in range(n_slots)] if self.side is not None else None
+        self.tail_done = [torch.cuda.Event() for _ in range(n_slots)] if self.side is not None else None
+        self._tail_used = [False] * n_slots
 
     def _views(self, buf: torch.Tensor):
         """[G, B, k] score / row views of a packed exchange buffer (strided over the rank blocks)."""
@@ -86,7 +98,7 @@ class ShardedSearch:
 
     def launch(self, slot: int):
         """Device phase of one query batch: shard search, all-gather, async copy (or device merge)."""
-        b = slot & 1
+        b = slot % self.n_slots
         if self.side is None:
             self._tail(slot, b)
             return
@@ -108,9 +120,9 @@ class ShardedSearch:
             gathered = torch.empty(self.world * self.block_bytes, dtype=torch.uint8)
             dist.all_gather_into_tensor(gathered, loc.cpu(), group=self.group)
             all_.copy_(gathered)
-        elif self.world > 1:
+        elif self.exchange:
             dist.all_gather_into_tensor(all_, loc, group=self.group)
-        if self.merge == "device" and self.world > 1:
+        if self.merge == "device" and self.exchange:
             s, r = _native.merge_topk(*self._views(all_), self.k)
             nb = self.B * self.k
             self.host[b][nb * 8: nb * 12].view(torch.float32).view(self.B, self.k).copy_(s, non_blocking=True)
@@ -122,10 +134,10 @@ class ShardedSearch:
 
     def finish(self, slot: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Host phase: wait for the batch's copy, merge G*k -> k per query.  Returns CPU tensors."""
-        b = slot & 1
+        b = slot % self.n_slots
         if self.copied is not None:
             self.copied[b].synchronize()
-        if self.world > 1 and self.merge == "host":
+        if self.exchange and self.merge == "host":
             return _native.merge_topk_host_packed(self.host[b], self.world, self.B, self.k, self.k)
         nb = self.B * self.k
         return (self.host[b][nb * 8: nb * 12].view(torch.float32).view(self.B, self.k),
