@@ -240,7 +240,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
     TopList<K> best;
     best.init();
     float thr = NEG_INF;
-    if (p.thr0 != nullptr && q0 + wn * 32 + r32 < p.B) thr = p.thr0[q0 + wn * 32 + r32];
+    if (q0 + wn * 32 + r32 >= p.B)
+        thr = INFINITY;  // padding query slot: its all-zero scores must never open the insertion path
+    else if (p.thr0 != nullptr)
+        thr = p.thr0[q0 + wn * 32 + r32];
 
     // ---- fragment addresses (bytes inside a stage) ------------------------------------------
     const int sw = (r32 >> 1) & 7;
@@ -302,7 +305,29 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
             ks = 0;
             const long long tile = (long long)p.tile0 + blockIdx.x + (long long)tile_idx * gridDim.x;
             const int row_base = (int)(tile * TM) + wm * (RM * 32) + 4 * h;
-            if constexpr (SEEDED) {
+            if constexpr (K > 5) {
+                // deep lists: one (not unrolled) insertion body per 4-row group keeps the code small
+                // (a K=20 insertion is ~100 instructions; 128 unrolled copies would not fit the I-cache)
+#pragma unroll
+                for (int b = 0; b < RM; ++b) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float a0 = acc[b][4 * g], a1 = acc[b][4 * g + 1];
+                        const float a2 = acc[b][4 * g + 2], a3 = acc[b][4 * g + 3];
+                        if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) >= thr) != 0ull) {
+#pragma clang loop unroll(disable)
+                            for (int i = 0; i < 4; ++i) {
+                                const float s = i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+                                const bool pass = s >= thr;
+                                if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                                    best.insert_strict(pass ? s : NEG_INF, row_base + b * 32 + i + 8 * g);
+                                    thr = fmaxf(thr, best.v[K - 1]);
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (SEEDED) {
                 // thresholds are warm from the first element (sample pre-pass): test 4 rows at a time
 #pragma unroll
                 for (int b = 0; b < RM; ++b) {
@@ -365,12 +390,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
         __syncthreads();
         const int t = threadIdx.x;
         if (t < QROWS && q0 + t < p.B) {
+            // every list is sorted (score desc, row asc) with its empty slots last: list 0 is taken as
+            // it stands, and a list is left at its first entry that does not make the merged top-K
             TopList<K> m;
-            m.init();
-            for (int i = 0; i < NL * K; ++i) {
-                const float x = ls[t * NL * K + i];
-                const int xr = lr[t * NL * K + i];
-                if (xr != INT_MAX && better(x, xr, m.v[K - 1], m.r[K - 1])) m.insert_ordered(x, xr);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                m.v[i] = ls[t * NL * K + i];
+                m.r[i] = lr[t * NL * K + i];
+            }
+            for (int l = 1; l < NL; ++l) {
+                for (int i = 0; i < K; ++i) {
+                    const float x = ls[(t * NL + l) * K + i];
+                    const int xr = lr[(t * NL + l) * K + i];
+                    if (xr == INT_MAX || !better(x, xr, m.v[K - 1], m.r[K - 1])) break;
+                    m.insert_ordered(x, xr);
+                }
             }
             const size_t base = ((size_t)(q0 + t) * p.n_lists + blockIdx.x) * K;
 #pragma unroll
@@ -517,10 +551,7 @@ struct Plan {
 Plan make_plan(int B, long long n, int k) {
     Plan pl;
     pl.K = k <= 5 ? 5 : (k <= 10 ? 10 : 20);
-    if (pl.K == 5)
-        pl.WN = B <= 64 ? 2 : (B <= 128 ? 4 : 8);
-    else
-        pl.WN = 2;  // deep lists: keep the unrolled epilogue small (32 accumulators per lane)
+    pl.WN = B <= 64 ? 2 : (B <= 128 ? 4 : 8);
     const int qrows = 32 * pl.WN;
     pl.grid_y = (B + qrows - 1) / qrows;
     pl.n_tiles = (int)((n + TM - 1) / TM);
@@ -528,11 +559,12 @@ Plan make_plan(int B, long long n, int k) {
     pl.grid_x = pl.n_tiles < cus ? pl.n_tiles : cus;
     if (pl.grid_x < 1) pl.grid_x = 1;
     pl.NW = (pl.K == 5 && pl.WN == 8 && !getenv("MMRAG_NW8")) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
-    // Sample pre-pass (256-query shape only: there the epilogue, not HBM, is what thresholds relieve).
+    // Sample pre-pass (256-query shape, and every shape with deep lists: there the epilogue, not HBM, is
+    // what thresholds relieve).
     // The exact top-K of the first `cus` tiles gives every query a threshold as tight as if each
     // workgroup had already seen 65k rows, so the main pass almost never takes the insertion path.
     pl.pre_tiles = 0;
-    if (pl.K == 5 && pl.WN == 8 && pl.n_tiles >= 3 * cus && !getenv("MMRAG_NO_PREPASS")) pl.pre_tiles = cus;
+    if ((pl.WN == 8 || pl.K > 5) && pl.n_tiles >= 3 * cus && !getenv("MMRAG_NO_PREPASS")) pl.pre_tiles = cus;
     pl.n_lists = pl.grid_x + (pl.pre_tiles ? 1 : 0);  // one merged list per workgroup per query (+ the sample's)
     pl.b_pad = pl.grid_y * qrows;
     return pl;
@@ -541,6 +573,15 @@ Plan make_plan(int B, long long n, int k) {
 template <int DT, int WN, int K, int NSTAGE, int NW = 8, bool SEEDED = false>
 void launch_main(const KParams &p, dim3 grid, hipStream_t s) {
     cosine_topk_kernel<DT, WN, K, NSTAGE, NW, SEEDED><<<grid, 64 * NW, 0, s>>>(p);
+}
+
+// deep lists (K = 10, 20): 8 waves (2 per SIMD, 256 registers each) hold the lists next to the accumulators
+template <int DT, int K>
+void dispatch_deep(const Plan &pl, const KParams &p, dim3 grid, hipStream_t s) {
+    if (pl.WN == 2) launch_main<DT, 2, K, 3>(p, grid, s);
+    else if (pl.WN == 4) launch_main<DT, 4, K, 3>(p, grid, s);
+    else if (p.thr0) launch_main<DT, 8, K, 2, 8, true>(p, grid, s);
+    else launch_main<DT, 8, K, 2>(p, grid, s);
 }
 
 template <int DT>
@@ -554,9 +595,9 @@ int dispatch_main(const Plan &pl, const KParams &p, hipStream_t s) {
         else if (p.thr0) launch_main<DT, 8, 5, 2, 8, true>(p, grid, s);
         else launch_main<DT, 8, 5, 2>(p, grid, s);
     } else if (pl.K == 10) {
-        launch_main<DT, 2, 10, 3>(p, grid, s);
+        dispatch_deep<DT, 10>(pl, p, grid, s);
     } else {
-        launch_main<DT, 2, 20, 3>(p, grid, s);
+        dispatch_deep<DT, 20>(pl, p, grid, s);
     }
     return MMRAG_OK;
 }
@@ -694,8 +735,10 @@ int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n,
         const long long n_cand = (long long)pre.grid_x * pl.K;
         launch_merge<int>(pl.K, p.cand_s, p.cand_r, n_cand, n_cand, 0, (long long)pl.n_lists * pl.K, B, pl.K, 0, top_s,
                           top_r, s);
-        seed_kernel<5><<<(unsigned)((B + 255) / 256), 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r,
-                                                                   pl.n_lists, pl.n_lists - 1);
+        const unsigned sg = (unsigned)((B + 255) / 256);
+        if (pl.K == 5) seed_kernel<5><<<sg, 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r, pl.n_lists, pl.n_lists - 1);
+        else if (pl.K == 10) seed_kernel<10><<<sg, 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r, pl.n_lists, pl.n_lists - 1);
+        else seed_kernel<20><<<sg, 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r, pl.n_lists, pl.n_lists - 1);
         MMRAG_CHECK_HIP(hipGetLastError());
         // 4. main pass over the remaining tiles, selection armed with the sample thresholds
         Plan mainp = pl;

@@ -88,6 +88,26 @@ def test_random_parity(N, dtype, B, n, d, k):
     check(*run(N, q, c, k, dtype))
 
 
+@pytest.mark.parametrize("B,n,d,k", [(130, 6000, 384, 10), (257, 5000, 768, 20), (100, 2000, 256, 20),
+                                      (200, 300_000, 128, 10), (256, 200_000, 64, 20)])
+def test_deep_lists_large_batches(N, B, n, d, k):
+    """k = 10 / 20 on the 128- and 256-query shapes; the two big cases take the sample pre-pass"""
+    q = unit_rows(B, d, 11)
+    c = unit_rows(n, d, 12)
+    check(*run(N, q, c, k, torch.float16))
+
+
+def test_deep_lists_exact_integers(N):
+    g = np.random.default_rng(6)
+    n, d, B = 210_000, 64, 160
+    c = g.integers(-3, 4, size=(n, d)).astype(np.float32)
+    q = g.integers(-3, 4, size=(B, d)).astype(np.float32)
+    for k in (10, 20):
+        s, r, es, er = run(N, q, c, k, torch.float16)
+        assert np.array_equal(s, es)
+        assert np.array_equal(r, er)  # heavy ties across tiles, workgroups and the sample pre-pass
+
+
 def test_exact_integers_catch_layout_swaps(N):
     """small-integer data is exact in fp16/fp32: any fragment/row-map mistake changes ids"""
     g = np.random.default_rng(5)

@@ -32,11 +32,17 @@ def bench(B, n, d, dtype, k=5, iters=20):
 
 if __name__ == "__main__":
     torch.cuda.init()
-    bench(256, 1_000_000, 768, torch.float16)
-    bench(256, 100_000, 384, torch.float32)
-    bench(1, 1_000_000, 768, torch.float16)
-    bench(32, 1_000_000, 768, torch.float16)
-    bench(128, 1_000_000, 768, torch.float16)
-    bench(256, 125_000, 768, torch.float16)
-    bench(1024, 1_000_000, 768, torch.float16)
-    bench(256, 1_000_000, 768, torch.float16, k=20)
+    f16, f32 = torch.float16, torch.float32
+    print("# C3 (1M x 768 fp16): whole corpus, then the per-GPU shards of N=2,4,8")
+    for n in (1_000_000, 500_000, 250_000, 125_000): bench(256, n, 768, f16)
+    print("# C2 (100k x 384 fp32, one GPU)")
+    for B in (1, 32, 256): bench(B, 100_000, 384, f32)
+    print("# C4 (600k x 512 fp16): whole and 1/8")
+    for n in (600_000, 75_000): bench(256, n, 512, f16)
+    print("# C5 (10M x 768 fp16, B=1024): the 1/8 shard")
+    bench(1024, 1_250_000, 768, f16)
+    print("# other batch sizes / depths at 1M x 768")
+    for B in (1, 32, 128): bench(B, 1_000_000, 768, f16)
+    for B in (32, 128, 256):
+        bench(B, 1_000_000, 768, f16, k=10); bench(B, 1_000_000, 768, f16, k=20)
+    bench(256, 1_000_000, 768, torch.bfloat16)
