@@ -180,6 +180,21 @@ int mmrag_vit_forward(const mmrag_encoder_desc *desc, const void *const *w, cons
                       const int32_t *cu_seqlens, int B, float *out, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* Image front end of the vision tower (BASELINE config 4; the reference has no image encoder):
+ * CLIP's preprocessing = shortest edge -> 224 with PIL bicubic, centre crop, done on uint8.  Bit-exact with
+ * Pillow's 8-bit resampler (two integer passes, 22-bit fixed-point taps).
+ *   mmrag_resample_ksize / mmrag_resample_coeffs   HOST: taps of output indices [first, first+count) of an
+ *       in_size -> out_size resample; bounds [count,2] = (first input index, tap count), taps [count, ksize].
+ *   mmrag_resize_crop_u8   DEVICE: src [H,W,3] uint8 (row stride src_row_bytes) -> dst [out_h,out_w,3] uint8 with
+ *       horizontal taps (bx,kx: per output COLUMN of the crop) then vertical taps (by,ky: per output ROW of the
+ *       crop); [y_lo,y_hi) = source rows the vertical taps touch; tmp holds (y_hi-y_lo)*out_w*3 bytes.
+ *       All table and image pointers are device pointers. */
+int mmrag_resample_ksize(int in_size, int out_size);
+int mmrag_resample_coeffs(int in_size, int out_size, int first, int count, int32_t *bounds, int32_t *taps);
+int mmrag_resize_crop_u8(const uint8_t *src, int H, int W, int64_t src_row_bytes, const int32_t *bx,
+                         const int32_t *kx, int ksx, const int32_t *by, const int32_t *ky, int ksy, int out_h,
+                         int out_w, int y_lo, int y_hi, uint8_t *tmp, uint8_t *dst, void *stream);
+
 /* The encoder's building blocks, exported so each kernel can be parity-tested on its own. */
 int mmrag_linear_f16(const void *x, int64_t M, int K, const void *wt, int N, const float *bias, int act,
                      const void *resid, void *out, void *stream);

@@ -65,6 +65,13 @@ def _declare(lib):
     lib.mmrag_vit_forward.restype = c_int
     lib.mmrag_vit_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                       c_void_p]
+    lib.mmrag_resample_ksize.restype = c_int
+    lib.mmrag_resample_ksize.argtypes = [c_int, c_int]
+    lib.mmrag_resample_coeffs.restype = c_int
+    lib.mmrag_resample_coeffs.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.mmrag_resize_crop_u8.restype = c_int
+    lib.mmrag_resize_crop_u8.argtypes = [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.mmrag_linear_f16.restype = c_int
     lib.mmrag_linear_f16.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p]
@@ -392,6 +399,39 @@ def vit_forward(desc: EncoderDesc, weight_ptrs, pixels: torch.Tensor, pixel_kind
                                      cu_seqlens.data_ptr(), B, out.data_ptr(), workspace.data_ptr(),
                                      workspace.numel() * workspace.element_size(), _stream_ptr(pixels.device))
     _check(st, "mmrag_vit_forward")
+    return out
+
+
+def resample_coeffs(in_size: int, out_size: int, first: int, count: int):
+    """HOST: Pillow's fixed-point bicubic taps of output indices [first, first+count).  Returns numpy
+    (bounds [count,2] int32, taps [count,ksize] int32).  No GPU needed."""
+    import numpy as np
+
+    ks = lib().mmrag_resample_ksize(in_size, out_size)
+    bounds = np.zeros((count, 2), np.int32)
+    taps = np.zeros((count, max(ks, 1)), np.int32)
+    _check(lib().mmrag_resample_coeffs(in_size, out_size, first, count, bounds.ctypes.data, taps.ctypes.data),
+           "mmrag_resample_coeffs")
+    return bounds, taps
+
+
+def resize_crop_u8(src: torch.Tensor, bx: torch.Tensor, kx: torch.Tensor, by: torch.Tensor, ky: torch.Tensor,
+                   y_lo: int, y_hi: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src [H,W,3] uint8 (device) -> [len(by), len(bx), 3] uint8: horizontal taps (bx,kx) per output column,
+    then vertical taps (by,ky) per output row; bit-exact with Pillow's 8-bit bicubic resize."""
+    _dev_check(src, bx, kx, by, ky, out)
+    if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3 or src.stride(2) != 1 or src.stride(1) != 3:
+        raise MMRagNativeError("resize_crop_u8: src must be [H, W, 3] uint8 with packed pixels")
+    H, W = int(src.shape[0]), int(src.shape[1])
+    out_h, out_w = int(by.shape[0]), int(bx.shape[0])
+    if out is None:
+        out = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=src.device)
+    tmp = torch.empty(((y_hi - y_lo) * out_w * 3,), dtype=torch.uint8, device=src.device)
+    with torch.cuda.device(src.device):
+        st = lib().mmrag_resize_crop_u8(src.data_ptr(), H, W, src.stride(0), bx.data_ptr(), kx.data_ptr(),
+                                        int(kx.shape[1]), by.data_ptr(), ky.data_ptr(), int(ky.shape[1]), out_h, out_w,
+                                        y_lo, y_hi, tmp.data_ptr(), out.data_ptr(), _stream_ptr(src.device))
+    _check(st, "mmrag_resize_crop_u8")
     return out
 
 

@@ -161,6 +161,30 @@ class DeviceClip:
     def random_init(cls, cfg: ClipConfig = VIT_B32, seed: int = 0, device="cuda:0") -> "DeviceClip":
         return cls(cfg, random_clip_weights(cfg, seed, device), device)
 
+    @classmethod
+    def from_local_dir(cls, path: str, device="cuda:0") -> "DeviceClip":
+        """Load a Hugging Face CLIPModel checkpoint directory (config.json + model.safetensors).
+        Nothing is downloaded; safetensors executes nothing from the file."""
+        import json
+        import os
+
+        from safetensors.numpy import load_file
+
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        t, v = c.get("text_config", {}), c.get("vision_config", {})
+        d = ClipConfig()
+        cfg = ClipConfig(
+            t.get("num_hidden_layers", d.t_layers), t.get("hidden_size", d.t_hidden),
+            t.get("num_attention_heads", d.t_heads), t.get("intermediate_size", d.t_inter),
+            t.get("vocab_size", d.vocab), t.get("max_position_embeddings", d.t_max_pos),
+            t.get("eos_token_id", d.eos_id) if t.get("eos_token_id", 2) != 2 else t.get("vocab_size", d.vocab) - 1,
+            v.get("num_hidden_layers", d.v_layers), v.get("hidden_size", d.v_hidden),
+            v.get("num_attention_heads", d.v_heads), v.get("intermediate_size", d.v_inter),
+            v.get("image_size", d.image), v.get("patch_size", d.patch), c.get("projection_dim", d.proj),
+            v.get("layer_norm_eps", d.ln_eps))
+        return cls(cfg, load_file(os.path.join(path, "model.safetensors")), device)
+
     @property
     def dim(self) -> int:
         return self.cfg.proj
@@ -206,3 +230,57 @@ class DeviceClip:
         c = self.cfg
         s = c.tokens_per_image
         return c.v_layers * s * (24.0 * c.v_hidden ** 2 + 4.0 * s * c.v_hidden) + 2.0 * (s - 1) * 3 * c.patch ** 2 * c.v_hidden
+
+
+def clip_resize_geometry(H: int, W: int, size: int = 224):
+    """CLIP processor geometry: shortest edge -> `size` (long edge = int(size * long / short)), centre crop.
+    Returns (new_h, new_w, top, left)."""
+    if H <= W:
+        new_h, new_w = size, int(size * W / H)
+    else:
+        new_h, new_w = int(size * H / W), size
+    return new_h, new_w, (new_h - size) // 2, (new_w - size) // 2
+
+
+class ClipImagePreprocessor:
+    """uint8 HWC images of any size -> [n, size, size, 3] uint8 on the device: the resize + centre crop of
+    CLIP's processor as two integer HIP passes (bit-exact with PIL bicubic); rescale + normalise stay fused
+    in the vision tower's patchify kernel.  Tap tables are computed on the host per source size and cached
+    on the device."""
+
+    def __init__(self, device="cuda:0", size: int = 224, max_cached_sizes: int = 64):
+        self.device = torch.device(device)
+        self.size = size
+        self._tables: Dict[tuple, tuple] = {}
+        self._max = max_cached_sizes
+
+    def tables(self, H: int, W: int):
+        key = (H, W)
+        t = self._tables.get(key)
+        if t is None:
+            new_h, new_w, top, left = clip_resize_geometry(H, W, self.size)
+            bx, kx = _native.resample_coeffs(W, new_w, left, self.size)
+            by, ky = _native.resample_coeffs(H, new_h, top, self.size)
+            y_lo = int(by[:, 0].min())
+            y_hi = int((by[:, 0] + by[:, 1]).max())
+            dev = [torch.from_numpy(a).to(self.device) for a in (bx, kx, by, ky)]
+            if len(self._tables) >= self._max:
+                self._tables.pop(next(iter(self._tables)))
+            t = self._tables[key] = (*dev, y_lo, y_hi)
+        return t
+
+    def __call__(self, images, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images: sequence of [H, W, 3] uint8 numpy arrays / tensors (host or device)."""
+        n = len(images)
+        if out is None:
+            out = torch.empty((n, self.size, self.size, 3), dtype=torch.uint8, device=self.device)
+        for i, img in enumerate(images):
+            if isinstance(img, np.ndarray) and not img.flags.writeable:
+                img = np.array(img)  # e.g. a PIL-backed view; torch wants writable memory
+            t = torch.as_tensor(img)
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise ValueError("images must be [H, W, 3] uint8 (RGB)")
+            t = t.contiguous().to(self.device, non_blocking=True)
+            bx, kx, by, ky, y_lo, y_hi = self.tables(int(t.shape[0]), int(t.shape[1]))
+            _native.resize_crop_u8(t, bx, kx, by, ky, y_lo, y_hi, out=out[i])
+        return out

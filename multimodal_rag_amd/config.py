@@ -43,6 +43,8 @@ class Settings:
     MMRAG_MODEL_DIR: str = field(default_factory=lambda: os.getenv("MMRAG_MODEL_DIR", ""))
     MMRAG_INDEX_DTYPE: str = field(default_factory=lambda: os.getenv("MMRAG_INDEX_DTYPE", "float16"))
     MMRAG_WEIGHT_SEED: int = field(default_factory=lambda: int(os.getenv("MMRAG_WEIGHT_SEED", "0")))
+    # CLIP engines only: embed image items from their pixels (vision tower) instead of their summary text
+    MMRAG_EMBED_IMAGE_PIXELS: bool = field(default_factory=lambda: _b("MMRAG_EMBED_IMAGE_PIXELS", "true"))
 
 
 settings = Settings()

@@ -119,3 +119,102 @@ class HashTokenizer:
         for w in basic_tokenize(text, self.lower)[: max_length - 2]:
             ids.append(1000 + int.from_bytes(hashlib.md5(w.encode("utf-8")).digest()[:8], "little") % span)
         return ids + [self.sep]
+
+
+# ---------------------------------------------------------------------------------------------
+# CLIP text tower: byte-level BPE (BASELINE config 4; no reference behaviour)
+# ---------------------------------------------------------------------------------------------
+def _bytes_to_unicode() -> Dict[int, str]:
+    """GPT-2's reversible byte -> printable character table (published with the CLIP tokenizer)."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return {b: chr(c) for b, c in zip(bs, cs)}
+
+
+class ClipBpeTokenizer:
+    """CLIP's lower-cased byte-level BPE over user-supplied LOCAL `vocab.json` + `merges.txt`
+    (the files that ship with openai/clip-vit-base-patch32; none can be fetched here).
+
+    Pipeline (as `transformers.CLIPTokenizer`, which the tests compare against on a synthetic
+    vocabulary): NFC -> collapse whitespace -> lower -> split with CLIP's pattern -> bytes to the
+    printable table -> merge pairs by rank with `</w>` on the last symbol -> ids;
+    `[<|startoftext|>] + ids[:max_length-2] + [<|endoftext|>]`.  ftfy's text repair (optional in
+    the original) is not applied."""
+
+    PATTERN = r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+"
+
+    def __init__(self, vocab: Dict[str, int], merges: List[str], context_length: int = 77):
+        import regex
+
+        self.vocab = vocab
+        self.ranks = {}
+        for i, line in enumerate(merges):
+            parts = line.split()
+            if len(parts) == 2:
+                self.ranks[(parts[0], parts[1])] = i
+        self.sot = vocab["<|startoftext|>"]
+        self.eot = vocab["<|endoftext|>"]
+        self.context_length = context_length
+        self.byte_chars = _bytes_to_unicode()
+        self._pat = regex.compile(self.PATTERN)
+        self._ws = regex.compile(r"\s+")
+        self._cache: Dict[str, List[int]] = {}
+
+    @classmethod
+    def from_files(cls, vocab_json: str, merges_txt: str, context_length: int = 77) -> "ClipBpeTokenizer":
+        import json
+
+        with open(vocab_json, encoding="utf-8") as f:
+            vocab = json.load(f)
+        with open(merges_txt, encoding="utf-8") as f:
+            lines = [ln.rstrip("\n") for ln in f]
+        if lines and lines[0].startswith("#"):
+            lines = lines[1:]
+        return cls(vocab, [ln for ln in lines if ln.strip()], context_length)
+
+    def _bpe(self, token: str) -> List[int]:
+        hit = self._cache.get(token)
+        if hit is not None:
+            return hit
+        word = [self.byte_chars[b] for b in token.encode("utf-8")]
+        word[-1] += "</w>"
+        while len(word) > 1:
+            best_rank, best_i = None, -1
+            for i in range(len(word) - 1):
+                r = self.ranks.get((word[i], word[i + 1]))
+                if r is not None and (best_rank is None or r < best_rank):
+                    best_rank, best_i = r, i
+            if best_rank is None:
+                break
+            first, second = word[best_i], word[best_i + 1]
+            merged, i = [], 0
+            while i < len(word):  # merge every occurrence of the best pair, left to right
+                if i + 1 < len(word) and word[i] == first and word[i + 1] == second:
+                    merged.append(first + second)
+                    i += 2
+                else:
+                    merged.append(word[i])
+                    i += 1
+            word = merged
+        ids = [self.vocab.get(w, self.eot) for w in word]  # unk_token is <|endoftext|>
+        self._cache[token] = ids
+        return ids
+
+    def encode(self, text: str, max_length: int = 0) -> List[int]:
+        max_length = max_length or self.context_length
+        text = self._ws.sub(" ", unicodedata.normalize("NFC", text)).lower()
+        ids: List[int] = []
+        for tok in self._pat.findall(text):
+            if tok == "<|startoftext|>":
+                ids.append(self.sot)
+            elif tok == "<|endoftext|>":
+                ids.append(self.eot)
+            else:
+                ids.extend(self._bpe(tok))
+        return [self.sot] + ids[: max(0, max_length - 2)] + [self.eot]

@@ -153,3 +153,102 @@ def preprocess_tiles(tiles_u8: np.ndarray) -> np.ndarray:
     """[B, H, W, 3] uint8 crops -> [B, 3, H, W] float32, (x/255 - mean)/std  (CLIP image normalisation)."""
     x = tiles_u8.astype(np.float32) / np.float32(255.0)
     return np.ascontiguousarray(((x - CLIP_MEAN) / CLIP_STD).transpose(0, 3, 1, 2)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Image front end: shortest-edge bicubic resize + centre crop on uint8 (what CLIP's processor does
+# with PIL).  Integer arithmetic, restated from Pillow's published 8-bit resampler (Resample.c:
+# precompute_coeffs / normalize_coeffs_8bpc / ImagingResampleHorizontal_8bpc / ..Vertical_8bpc);
+# pinned bit-exactly against PIL.Image.resize and transformers.CLIPImageProcessor in
+# tests/golden/make_resize_golden.py.  Test infrastructure only.
+# ---------------------------------------------------------------------------------------------
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_coeffs(in_size: int, out_size: int):
+    """Per output index: (first input index, tap count) and fixed-point taps, as Pillow computes them
+    for the bicubic filter over the whole input extent.  Returns (bounds [out,2] int32, taps [out,ksize] int32)."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    taps = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        for x, w in enumerate(k):
+            taps[xx, x] = int(-0.5 + w * (1 << PRECISION_BITS)) if w < 0 else int(0.5 + w * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, taps
+
+
+def _clip8(acc: np.ndarray) -> np.ndarray:
+    return np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resize_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """PIL.Image.resize((out_w, out_h), BICUBIC) of an [H, W, C] uint8 image: horizontal pass, round to
+    uint8, vertical pass, round to uint8."""
+    H, W, C = img.shape
+    src = img.astype(np.int64)
+    if out_w != W:
+        bx, kx = resample_coeffs(W, out_w)
+        tmp = np.empty((H, out_w, C), np.uint8)
+        for xx in range(out_w):
+            x0, n = bx[xx]
+            acc = (src[:, x0:x0 + n, :] * kx[xx, :n].astype(np.int64)[None, :, None]).sum(axis=1) + (1 << (PRECISION_BITS - 1))
+            tmp[:, xx, :] = _clip8(acc)
+        src = tmp.astype(np.int64)
+    else:
+        tmp = img
+    if out_h != H:
+        by, ky = resample_coeffs(H, out_h)
+        out = np.empty((out_h, src.shape[1], C), np.uint8)
+        for yy in range(out_h):
+            y0, n = by[yy]
+            acc = (src[y0:y0 + n] * ky[yy, :n].astype(np.int64)[:, None, None]).sum(axis=0) + (1 << (PRECISION_BITS - 1))
+            out[yy] = _clip8(acc)
+        return out
+    return np.ascontiguousarray(tmp)
+
+
+def clip_resize_geometry(H: int, W: int, size: int = 224):
+    """Shortest edge -> `size` keeping aspect (long edge = int(size * long / short)), then the centre
+    crop's top-left corner.  Returns (new_h, new_w, top, left)."""
+    if H <= W:
+        new_h, new_w = size, int(size * W / H)
+    else:
+        new_h, new_w = int(size * H / W), size
+    return new_h, new_w, (new_h - size) // 2, (new_w - size) // 2
+
+
+def clip_resize_crop_u8(img: np.ndarray, size: int = 224) -> np.ndarray:
+    """[H, W, 3] uint8 -> [size, size, 3] uint8: CLIP's resize + centre crop, before rescale/normalise."""
+    new_h, new_w, top, left = clip_resize_geometry(img.shape[0], img.shape[1], size)
+    r = resize_u8(img, new_h, new_w)
+    return np.ascontiguousarray(r[top:top + size, left:left + size])

@@ -233,3 +233,54 @@ def test_dispatcher_batches_concurrent_queries():
             await m.query("  ")
         await m.cleanup()
     run(main())
+
+
+# ---------------------------------------------------------------- joint-space engines: image items by pixels
+class FakeJointEngine(FakeEngine):
+    """adds encode_images: the vector is keyed on the mean pixel, so tests can tell which path was taken"""
+
+    def __init__(self):
+        super().__init__()
+        self.image_calls = []
+
+    def encode_images(self, images):
+        self.image_calls.append([im.shape for im in images])
+        out = np.zeros((len(images), self.dim), np.float32)
+        for i, im in enumerate(images):
+            out[i, int(im.mean()) % self.dim] = 1.0
+        return out
+
+
+def test_image_items_are_embedded_from_pixels_on_joint_engines(tmp_path):
+    import base64
+    import io
+
+    Image = pytest.importorskip("PIL.Image")
+    eng = FakeJointEngine()
+    m = EmbeddingManager(engine=eng)
+    m._sleep = no_sleep
+    png = tmp_path / "fig.png"
+    Image.fromarray(np.full((40, 60, 3), 7, np.uint8)).save(png)
+    buf = io.BytesIO()
+    Image.fromarray(np.full((30, 30, 3), 9, np.uint8)).save(buf, format="PNG")
+    items = [
+        {"id": "text_0", "summary": "plain text", "raw": "plain text", "type": "text"},
+        {"id": "image_0", "summary": "a figure", "raw": "", "type": "image", "path": str(png)},
+        {"id": "image_1", "summary": "inline figure", "raw": base64.b64encode(buf.getvalue()).decode(), "type": "image"},
+        {"id": "image_2", "summary": "undecodable figure", "raw": "not an image", "type": "image"},
+    ]
+    counts = run(m.embed_and_store(items, "doc_aaaaaaaaaaaa"))
+    assert counts == {"text": 1, "table": 0, "image": 3}
+    assert eng.image_calls == [[(40, 60, 3), (30, 30, 3)]]
+    got = m.collection.get(ids=[f"doc_aaaaaaaaaaaa_{it['id']}" for it in items], include=["embeddings", "documents"])
+    E = np.asarray(got["embeddings"], np.float32)
+    assert E[1, 7] == 1.0 and E[2, 9] == 1.0                       # pixel path
+    assert np.allclose(E[0], eng.encode(["plain text"])[0]) and np.allclose(E[3], eng.encode(["undecodable figure"])[0])
+    assert got["documents"][1] == "a figure"                        # the stored document is still the summary
+
+
+def test_text_only_engines_keep_reference_behaviour_for_images():
+    m, eng = manager()
+    items = summaries(3, kinds=("image",))
+    run(m.embed_and_store(items, "doc_bbbbbbbbbbbb"))
+    assert not hasattr(eng, "encode_images") and eng.calls == [3]   # embedder.py:452: summaries are what is embedded

@@ -112,6 +112,43 @@ def test_embedding_manager_on_hip_engine(gpu, golden_dir):
     run(m.cleanup())
 
 
+def test_clip_engine_joint_space(gpu, golden_dir, tmp_path):
+    """BASELINE config 4: text chunks and images of arbitrary size in ONE index (CLIP ViT-B/32 shape, random
+    weights); vectors must equal the towers driven directly, and search over the mixed index matches the oracle."""
+    from PIL import Image
+
+    from multimodal_rag_amd.embedder import ClipEngine, EmbeddingManager
+    from tests.golden.make_resize_golden import formula_image
+
+    eng = ClipEngine("openai/clip-vit-base-patch32")
+    m = EmbeddingManager(engine=eng)
+    run(m.initialize())
+    assert m.get_embedding_dimension() == 512
+    sizes = [(300, 420), (640, 480), (224, 224), (90, 700)]
+    items = [{"id": f"text_{i}", "summary": f"chunk {i} about topic {i % 5}", "raw": "", "type": "text"} for i in range(40)]
+    for j, (H, W) in enumerate(sizes):
+        p = tmp_path / f"img{j}.png"
+        Image.fromarray(formula_image(H, W)).save(p)
+        items.append({"id": f"image_{j}", "summary": f"figure {j}", "raw": "", "type": "image", "path": str(p)})
+    assert run(m.embed_and_store(items, "doc_c11bc11bc11b")) == {"text": 40, "table": 0, "image": 4}
+
+    ids = [f"doc_c11bc11bc11b_{it['id']}" for it in items]
+    stored = np.asarray(m.collection.get(ids=ids, include=["embeddings"])["embeddings"], np.float32)
+    want_img = eng.clip.encode_images(eng.preprocess([formula_image(H, W) for H, W in sizes])).cpu().numpy()
+    want_txt = eng.encode([it["summary"] for it in items[:40]])
+    assert np.abs(stored[40:] - want_img).max() <= 1e-3 and np.abs(stored[:40] - want_txt).max() <= 1e-3
+    assert np.allclose(np.linalg.norm(stored, axis=1), 1, atol=2e-3)
+
+    q = "figure 2"
+    r = run(m.query(q, n_results=5))
+    qe = np.asarray(run(m.embed_texts_batch([q])), np.float32).astype(np.float16).astype(np.float32)
+    es, er = O.cosine_topk(qe, stored, 5)
+    assert O.same_topk_sets(np.array([[ids.index(i) for i in r["ids"]]]), 1 - np.array([r["distances"]]), er, es)
+    only_img = run(m.query(q, n_results=3, filter_dict={"type": "image"}))
+    assert all(md["type"] == "image" for md in only_img["metadatas"])
+    run(m.cleanup())
+
+
 def test_fastapi_surface_on_gpu(gpu, golden_dir):
     from starlette.testclient import TestClient
 

@@ -36,3 +36,45 @@ def test_hash_tokenizer_is_deterministic_and_in_range():
     assert a[0] == 101 and a[-1] == 102 and all(1000 <= x < 30522 for x in a[1:-1])
     assert len(t.encode("word " * 1000, 256)) == 256
     assert t.encode("", 256) == [101, 102]
+
+
+# ---- CLIP byte-level BPE -------------------------------------------------------------------
+import json
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _clip_tok():
+    from multimodal_rag_amd.tokenizer import ClipBpeTokenizer
+
+    return ClipBpeTokenizer.from_files(os.path.join(GOLD, "clip_bpe_vocab.json"), os.path.join(GOLD, "clip_bpe_merges.txt"))
+
+
+def test_clip_bpe_matches_committed_golden():
+    """ids produced by transformers.CLIPTokenizer on the synthetic vocabulary (make_clip_bpe_golden.py)"""
+    exp = json.load(open(os.path.join(GOLD, "clip_bpe_expected.json"), encoding="utf-8"))
+    tk = _clip_tok()
+    assert (tk.sot, tk.eot) == (exp["sot"], exp["eot"])
+    for c in exp["cases"]:
+        assert tk.encode(c["text"]) == c["ids"], c["text"]
+        assert tk.encode(c["text"], 16) == c["ids_16"], c["text"]
+
+
+def test_clip_bpe_matches_transformers_live():
+    transformers = pytest.importorskip("transformers")
+    tk = _clip_tok()
+    vocab = json.load(open(os.path.join(GOLD, "clip_bpe_vocab.json"), encoding="utf-8"))
+    merges = [tuple(ln.split()) for ln in open(os.path.join(GOLD, "clip_bpe_merges.txt"), encoding="utf-8")
+              if ln.strip() and not ln.startswith("#")]
+    ref = transformers.CLIPTokenizer(vocab=vocab, merges=merges)
+    for t in ["Figure 3: throughput vs. batch size", "don't you'll we've I'm", "tab\tsep  x1y2z3", "ÀÉÎ õ ß", "🙂 emoji"]:
+        assert tk.encode(t) == ref(t, truncation=True, max_length=77)["input_ids"], t
+
+
+def test_clip_bpe_shape_rules():
+    tk = _clip_tok()
+    ids = tk.encode("retrieval " * 200)
+    assert len(ids) == 77 and ids[0] == tk.sot and ids[-1] == tk.eot
+    assert tk.encode("") == [tk.sot, tk.eot]
+    assert tk.eot == max(tk.vocab.values())  # EOS pooling picks argmax(id): the end token must be the largest id
