@@ -239,6 +239,11 @@ class VectorIndex:
                     out["embeddings"].append(self._fetch(hit))
             return out
 
+    def ids_of_rows(self, rows: Sequence[int]) -> List[str]:
+        """ids of the given local rows (row numbers are only stable until the next delete)."""
+        with self._lock:
+            return [self._ids[int(r)] for r in rows]
+
     def _fetch(self, rows: List[int]) -> List[List[float]]:
         if not rows:
             return []

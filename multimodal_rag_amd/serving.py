@@ -1,0 +1,287 @@
+"""Multi-GPU serving loop around the row-sharded index.
+
+One process per GPU.  Rank 0 owns the public surface (`EmbeddingManager`, FastAPI) and drives a
+`ShardedCollection`, which has the collection interface the embedder expects (add / query / get /
+delete / count / reset); every other rank sits in `worker_loop()` and executes the same command
+on its own shard.  A shard is anything with `VectorIndex`'s methods -- on the GPU it IS a
+`VectorIndex` (rows in HBM, fused cosine top-k kernel), in the CPU tests a numpy stand-in.
+
+Query data path (the part BASELINE measures, same sequence as `ShardedSearch`):
+    rank 0 broadcasts the command and the query matrix
+    every rank:  shard.search(q, k, where)            local top-k, local row numbers
+                 pack [sequence no. i64 | score f32]  sequence no. = global insertion order of the row
+                 ONE all-gather of the packed blocks  (RCCL on GPUs, gloo in the CPU tests)
+                 host merge G*k -> k  (mmrag_merge_topk_host_packed; every rank runs it: the
+                                       winners tell each rank which of its rows to describe)
+                 gather_object(payload of my winning rows) -> rank 0
+    rank 0 assembles the Chroma-shaped result.
+Ties are broken by (score desc, sequence number asc) = earlier insert first, the rule of a single
+`VectorIndex`, so the answer does not depend on how many ranks share the corpus.
+Ingest: rank 0 assigns each new item to the emptiest shard and broadcasts the batch; each rank
+keeps its part.  Ids, documents and metadata live with their rows, on the owning rank's host.
+
+The reference is single-process; nothing here replaces reference code.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+logger = logging.getLogger(__name__)
+
+
+class ShardedCollection:
+    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None):
+        """`shard`: this rank's VectorIndex (or stand-in).  `device`: where collective buffers live
+        (the shard's GPU with the nccl backend, CPU with gloo)."""
+        self.shard = shard
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.name = getattr(shard, "name", "sharded")
+        self.metadata = getattr(shard, "metadata", None)
+        self._owner: Dict[str, int] = {}          # rank 0 only: id -> owning rank
+        self._counts = [0] * self.world           # rank 0 only: rows per shard
+        self._next_seq = 0                        # rank 0 only: global insertion counter
+        self._seq_of: Dict[str, int] = {}         # this rank's rows: id -> sequence number
+        self._id_of: Dict[int, str] = {}          # ... and back
+        # the embedder calls the collection from asyncio.to_thread workers (embedder.py:517, 595): one
+        # command (= one sequence of collectives) at a time per communicator
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ control plane -------
+    def _command(self, cmd: Optional[Dict[str, Any]]) -> Dict[str, Any]:
+        box = [cmd]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
+
+    def _gather(self, obj: Any) -> Optional[List[Any]]:
+        out = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(obj, out, dst=0, group=self.group)
+        return out
+
+    def _require_rank0(self):
+        if self.rank != 0:
+            raise RuntimeError("collection methods are driven from rank 0; other ranks run worker_loop()")
+
+    def worker_loop(self):
+        """Ranks != 0: execute rank 0's commands until it sends 'stop'."""
+        if self.rank == 0:
+            raise RuntimeError("rank 0 drives the collection; worker_loop() is for the other ranks")
+        while True:
+            cmd = self._command(None)
+            if cmd["op"] == "stop":
+                return
+            self._execute(cmd)
+
+    def stop(self):
+        self._require_rank0()
+        with self._lock:
+            self._command({"op": "stop"})
+
+    def _execute(self, cmd: Dict[str, Any]):
+        return getattr(self, "_do_" + cmd["op"])(cmd)
+
+    def _run(self, cmd: Dict[str, Any]):
+        """rank 0: broadcast a command and take part in it, one at a time"""
+        with self._lock:
+            return self._execute(self._command(cmd))
+
+    # ------------------------------------------------------------------ add -----------------
+    def add(self, embeddings, documents=None, metadatas=None, ids: Optional[Sequence[str]] = None):
+        self._require_rank0()
+        n = len(embeddings)
+        if ids is None or len(ids) != n:
+            raise ValueError("ids are required, one per embedding")
+        documents = list(documents) if documents is not None else [None] * n
+        metadatas = list(metadatas) if metadatas is not None else [{} for _ in range(n)]
+        with self._lock:
+            parts: Dict[int, Dict[str, Any]] = {}
+            for i in range(n):
+                if ids[i] in self._owner:        # duplicate id: ignored, as VectorIndex.add does
+                    continue
+                r = int(np.argmin(self._counts))
+                self._owner[ids[i]] = r
+                self._counts[r] += 1
+                p = parts.setdefault(r, {"embeddings": [], "documents": [], "metadatas": [], "ids": [], "seqs": []})
+                p["seqs"].append(self._next_seq)
+                self._next_seq += 1
+                p["embeddings"].append(embeddings[i])
+                p["documents"].append(documents[i])
+                p["metadatas"].append(metadatas[i])
+                p["ids"].append(ids[i])
+            for p in parts.values():
+                p["embeddings"] = np.asarray(p["embeddings"], dtype=np.float32)
+            self._execute(self._command({"op": "add", "parts": parts}))
+
+    def _do_add(self, cmd):
+        p = cmd["parts"].get(self.rank)
+        if p:
+            self.shard.add(p["embeddings"], documents=p["documents"], metadatas=p["metadatas"], ids=p["ids"])
+            for i, sq in zip(p["ids"], p["seqs"]):
+                self._seq_of[i] = sq
+                self._id_of[sq] = i
+
+    # ------------------------------------------------------------------ query ---------------
+    def query(self, query_embeddings, n_results: int = 10, where: Optional[Dict[str, Any]] = None,
+              include: Sequence[str] = ("metadatas", "documents", "distances")) -> Dict[str, Any]:
+        self._require_rank0()
+        q = np.asarray(query_embeddings, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        return self._run({"op": "query", "q": q, "k": int(n_results), "where": where, "include": tuple(include)})
+
+    def _do_query(self, cmd):
+        q, k, where, include = cmd["q"], cmd["k"], cmd["where"], cmd["include"]
+        B = q.shape[0]
+        scores, rows = self.shard.search(q, k, where)            # [B, k'] desc, local rows, -1 = none
+        scores = torch.as_tensor(scores).to(torch.float32)
+        rows = torch.as_tensor(rows).to(torch.int64)
+        kk = scores.shape[1]
+        if kk < k:                                               # shard returned fewer columns than asked
+            pad = k - kk
+            scores = torch.cat([scores, torch.full((B, pad), float("-inf"), dtype=scores.dtype, device=scores.device)], 1)
+            rows = torch.cat([rows, torch.full((B, pad), -1, dtype=rows.dtype, device=rows.device)], 1)
+        # local row -> global sequence number (host tables; the serving loop is synchronous anyway)
+        rows_h = rows.cpu().numpy()
+        live = sorted({int(r) for r in rows_h.reshape(-1) if r >= 0})
+        seq_of_row = {r: self._seq_of[i] for r, i in zip(live, self.shard.ids_of_rows(live))}
+        seqs = np.array([[seq_of_row[int(r)] if r >= 0 else -1 for r in row] for row in rows_h], np.int64).reshape(B, k)
+        # ONE packed block per rank: [sequence numbers B*k i64 | scores B*k f32 | pad]
+        nb = B * k
+        nbytes = _native.packed_block_bytes(B, k)
+        loc = torch.zeros(nbytes, dtype=torch.uint8)
+        loc[: nb * 8].view(torch.int64).copy_(torch.from_numpy(seqs).reshape(-1))
+        loc[nb * 8: nb * 12].view(torch.float32).copy_(scores.reshape(-1).cpu())
+        loc = loc.to(self.device)
+        all_ = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(all_, loc, group=self.group)
+        host = all_.cpu()
+        if k <= _native.MAX_K:
+            top_s, top_r = _native.merge_topk_host_packed(host, self.world, B, k, k)
+            top_s, top_r = top_s.numpy(), top_r.numpy()
+        else:
+            top_s, top_r = _merge_deep(host, self.world, B, k)
+        # describe the winning rows this rank owns
+        mine: Dict[int, Dict[str, Any]] = {}
+        owned = sorted({int(sq) for sq in top_r.reshape(-1) if sq >= 0 and int(sq) in self._id_of})
+        if owned:
+            got = self.shard.get(ids=[self._id_of[sq] for sq in owned],
+                                 include=tuple(x for x in include if x != "distances"))
+            at = {i: j for j, i in enumerate(got["ids"])}
+            for sq in owned:
+                j = at[self._id_of[sq]]
+                mine[sq] = {"id": self._id_of[sq],
+                            "metadata": got["metadatas"][j] if got.get("metadatas") is not None else None,
+                            "document": got["documents"][j] if got.get("documents") is not None else None,
+                            "embedding": got["embeddings"][j] if got.get("embeddings") is not None else None}
+        payloads = self._gather(mine)
+        if self.rank != 0:
+            return None
+        out: Dict[str, Any] = {"ids": []}
+        for key in ("distances", "metadatas", "documents", "embeddings"):
+            out[key] = [] if key in include else None
+        where_is = {}
+        for g, p in enumerate(payloads):
+            for sq in p:
+                where_is[sq] = g
+        for b in range(B):
+            hits = [(where_is[int(sq)], int(sq), float(sc)) for sq, sc in zip(top_r[b], top_s[b]) if sq >= 0]
+            out["ids"].append([payloads[g][sq]["id"] for g, sq, _ in hits])
+            if "distances" in include:
+                out["distances"].append([float(np.float32(1.0) - np.float32(sc)) for _, _, sc in hits])
+            for key, field in (("metadatas", "metadata"), ("documents", "document"), ("embeddings", "embedding")):
+                if key in include:
+                    out[key].append([payloads[g][sq][field] for g, sq, _ in hits])
+        return out
+
+    # ------------------------------------------------------------------ get / delete / count -
+    def get(self, ids: Optional[Sequence[str]] = None, where: Optional[Dict[str, Any]] = None,
+            include: Sequence[str] = ("metadatas", "documents")) -> Dict[str, Any]:
+        self._require_rank0()
+        return self._run({"op": "get", "ids": list(ids) if ids is not None else None, "where": where,
+                          "include": tuple(include)})
+
+    def _do_get(self, cmd):
+        res = self.shard.get(ids=cmd["ids"], where=cmd["where"], include=cmd["include"])
+        parts = self._gather(res)
+        if self.rank != 0:
+            return None
+        rows = []
+        for p in parts:
+            for j, i in enumerate(p["ids"]):
+                rows.append((i, {k: (p[k][j] if p.get(k) is not None else None)
+                                 for k in ("metadatas", "documents", "embeddings")}))
+        if cmd["ids"] is not None:                      # requested order, as a single index answers
+            order = {s: n for n, s in enumerate(cmd["ids"])}
+            rows.sort(key=lambda t: order.get(t[0], len(order)))
+        out: Dict[str, Any] = {"ids": [r[0] for r in rows]}
+        for k in ("metadatas", "documents", "embeddings"):
+            out[k] = [r[1][k] for r in rows] if k in cmd["include"] else None
+        return out
+
+    def delete(self, ids: Optional[Sequence[str]] = None, where: Optional[Dict[str, Any]] = None) -> List[str]:
+        self._require_rank0()
+        return self._run({"op": "delete", "ids": list(ids) if ids is not None else None, "where": where})
+
+    def _do_delete(self, cmd):
+        gone = self.shard.delete(ids=cmd["ids"], where=cmd["where"])
+        for i in gone:
+            self._id_of.pop(self._seq_of.pop(i), None)
+        parts = self._gather(gone)
+        if self.rank != 0:
+            return None
+        out = []
+        for g, p in enumerate(parts):
+            for i in p:
+                self._owner.pop(i, None)
+                self._counts[g] -= 1
+                out.append(i)
+        return sorted(out)
+
+    def count(self) -> int:
+        self._require_rank0()
+        return self._run({"op": "count"})
+
+    def _do_count(self, cmd):
+        parts = self._gather(self.shard.count())
+        return sum(parts) if self.rank == 0 else None
+
+    def reset(self):
+        self._require_rank0()
+        with self._lock:
+            self._execute(self._command({"op": "reset"}))
+            self._owner.clear()
+            self._counts = [0] * self.world
+            self._next_seq = 0
+
+    def _do_reset(self, cmd):
+        self.shard.reset()
+        self._seq_of.clear()
+        self._id_of.clear()
+
+
+def _merge_deep(host: torch.Tensor, G: int, B: int, k: int):
+    """k > MAX_K (single deep queries, get_similar_documents): same order rule as the C++ merge
+    (score desc, lower sequence number on ties) over the G*k candidates, in numpy."""
+    nb = B * k
+    nbytes = _native.packed_block_bytes(B, k)
+    blocks = host.view(G, nbytes)
+    rows = np.stack([blocks[g, : nb * 8].view(torch.int64).view(B, k).numpy() for g in range(G)], 1).reshape(B, G * k)
+    scores = np.stack([blocks[g, nb * 8: nb * 12].view(torch.float32).view(B, k).numpy() for g in range(G)], 1).reshape(B, G * k)
+    out_s = np.full((B, k), -np.inf, np.float32)
+    out_r = np.full((B, k), -1, np.int64)
+    for b in range(B):
+        ok = np.nonzero((rows[b] >= 0) & np.isfinite(scores[b]))[0]
+        order = ok[np.lexsort((rows[b][ok], -scores[b][ok]))][:k]
+        out_s[b, : len(order)] = scores[b][order]
+        out_r[b, : len(order)] = rows[b][order]
+    return out_s, out_r

@@ -32,10 +32,14 @@ class FakeCollection:
     def add(self, embeddings, documents=None, metadatas=None, ids=None):
         self._maybe_fail()
         e = np.asarray(embeddings, np.float32).reshape(-1, self.dim)
-        self.vecs = np.concatenate([self.vecs, e])
-        self.ids += list(ids)
-        self.docs += list(documents or [None] * len(ids))
-        self.metas += [dict(m) for m in (metadatas or [{}] * len(ids))]
+        documents = list(documents or [None] * len(ids))
+        metadatas = list(metadatas or [{}] * len(ids))
+        have = set(self.ids)
+        new = [j for j, i in enumerate(ids) if not (i in have or have.add(i))]   # duplicate ids ignored, as VectorIndex
+        self.vecs = np.concatenate([self.vecs, e[new]])
+        self.ids += [ids[j] for j in new]
+        self.docs += [documents[j] for j in new]
+        self.metas += [dict(metadatas[j]) for j in new]
 
     def query(self, query_embeddings, n_results=10, where=None, include=("metadatas", "documents", "distances")):
         self._maybe_fail()
@@ -52,8 +56,26 @@ class FakeCollection:
             out["documents"].append([self.docs[i] for i in hit])
         return out
 
+    # ---- the row-level half of VectorIndex (what serving.ShardedCollection drives on each rank)
+    def search(self, query_embeddings, n_results, where=None):
+        q = np.asarray(query_embeddings, np.float32).reshape(-1, self.dim)
+        if not self.ids:
+            return np.full((len(q), n_results), -np.inf, np.float32), np.full((len(q), n_results), -1, np.int64)
+        alive = np.array([match_where(m, where) for m in self.metas], bool) if where else None
+        return O.cosine_topk(q, self.vecs, n_results, alive=alive)
+
+    def ids_of_rows(self, rows):
+        return [self.ids[int(r)] for r in rows]
+
+    def reset(self):
+        self.__init__(self.dim, self.name, self.metadata)
+
     def get(self, ids=None, where=None, include=("metadatas", "documents")):
-        rows = [i for i, s in enumerate(self.ids) if (ids is None or s in ids) and match_where(self.metas[i], where)]
+        if ids is not None:      # requested order, as VectorIndex.get
+            at = {s: i for i, s in enumerate(self.ids)}
+            rows = [at[s] for s in ids if s in at and match_where(self.metas[at[s]], where)]
+        else:
+            rows = [i for i in range(len(self.ids)) if match_where(self.metas[i], where)]
         return {"ids": [self.ids[i] for i in rows], "metadatas": [self.metas[i] for i in rows],
                 "documents": [self.docs[i] for i in rows],
                 "embeddings": [self.vecs[i].tolist() for i in rows] if "embeddings" in include else None}
@@ -65,6 +87,7 @@ class FakeCollection:
         self.ids = [self.ids[i] for i in keep]
         self.docs = [self.docs[i] for i in keep]
         self.metas = [self.metas[i] for i in keep]
+        return sorted(kill)
 
 
 class FakeEngine:

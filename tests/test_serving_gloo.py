@@ -1,0 +1,137 @@
+"""CPU, multi-process (gloo): the multi-GPU serving loop (serving.ShardedCollection).  Rank 0 drives the
+collection -- directly and through EmbeddingManager -- while the other ranks run worker_loop(); every
+answer must equal what ONE collection holding all rows gives (the oracle stands in for the shard kernel)."""
+import asyncio
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from multimodal_rag_amd.serving import ShardedCollection
+from tests.fakes import FakeCollection, FakeEngine
+
+D = 32
+
+
+def data(n=157):
+    """small-integer vectors: every dot product is exact in float32 whatever the shard split, and equal
+    scores are frequent, so the order of the answers exercises the insertion-order tie rule"""
+    g = np.random.default_rng(21)
+    v = g.integers(-2, 3, size=(n, D)).astype(np.float32)
+    v[100] = v[3]                                   # duplicate vector, lands on another shard
+    ids = [f"doc_{i // 50:012x}_text_{i}" for i in range(n)]
+    metas = [{"doc_id": i_[:16], "item_id": i_[17:], "type": "image" if i % 4 == 0 else "text"} for i, i_ in enumerate(ids)]
+    docs = [f"document {i}" for i in range(n)]
+    q = g.integers(-2, 3, size=(9, D)).astype(np.float32)
+    q[0] = v[3]
+    return v, ids, metas, docs, q
+
+
+def script(col):
+    """the same calls against a sharded and a single collection; returns a JSON-able transcript"""
+    v, ids, metas, docs, q = data()
+    out = {}
+    for lo in range(0, len(ids), 40):               # several adds, one duplicate id batch
+        col.add(v[lo:lo + 40].tolist(), documents=docs[lo:lo + 40], metadatas=metas[lo:lo + 40], ids=ids[lo:lo + 40])
+    col.add(v[:2].tolist(), documents=["dup", "dup"], metadatas=metas[:2], ids=ids[:2])
+    out["count"] = col.count()
+    out["q5"] = col.query(q.tolist(), n_results=5)
+    out["q5_img"] = col.query(q.tolist(), n_results=5, where={"type": "image"})
+    out["q1_deep"] = col.query(q[:1].tolist(), n_results=31, include=("distances",))
+    out["q_more_than_rows"] = col.query(q[:2].tolist(), n_results=20, where={"doc_id": "doc_000000000003"})
+    out["get_ids"] = col.get(ids=[ids[77], ids[3], "missing", ids[150]], include=("documents", "metadatas"))
+    out["deleted"] = col.delete(where={"doc_id": "doc_000000000001"})
+    out["count_after"] = col.count()
+    out["q5_after"] = col.query(q.tolist(), n_results=5)
+    out["get_where"] = sorted(col.get(where={"type": "image"}, include=())["ids"])
+    return out
+
+
+def manager_script(m):
+    async def go():
+        await m.initialize()
+        items = [{"id": f"text_{i}", "summary": f"summary number {i}", "raw": "", "type": "text"} for i in range(60)]
+        counts = await m.embed_and_store(items, "doc_feedfeedfeed")
+        r = await m.query("summary number 17", n_results=5)
+        b = await m.batch_query(["summary number 3", "summary number 44"], n_results=3)
+        sim = await m.get_similar_documents("doc_feedfeedfeed", "text_5", n_results=4)
+        stats = await m.get_collection_stats()
+        await m.delete_document("doc_feedfeedfeed")
+        left = (await m.get_collection_stats())["count"]
+        return {"counts": counts, "r": r, "b": b, "sim": sim, "count": stats["count"], "left": left}
+
+    return asyncio.run(go())
+
+
+class ShardedEngine(FakeEngine):
+    """FakeEngine whose collections are sharded over the process group"""
+
+    def new_collection(self, name, metadata=None):
+        return ShardedCollection(FakeCollection(self.dim, name, metadata))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        col = ShardedCollection(FakeCollection(D))
+        if rank == 0:
+            out = script(col)
+            out["shard_counts"] = list(col._counts)
+            col.stop()
+        else:
+            col.worker_loop()
+        # second phase: the collection behind EmbeddingManager
+        from multimodal_rag_amd.embedder import EmbeddingManager
+
+        eng = ShardedEngine(D)
+        m = EmbeddingManager(engine=eng)
+        if rank == 0:
+            out["manager"] = manager_script(m)
+            m.collection.stop()
+            json.dump(out, open(os.path.join(out_dir, f"sharded_{world}.json"), "w"))
+        else:
+            eng.new_collection("multimodal_rag").worker_loop()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _close(a, b):
+    if isinstance(a, float) or isinstance(b, float):
+        return abs(a - b) <= 1e-6
+    if isinstance(a, dict):
+        # include-dependent keys may be None or absent (the numpy stand-in ignores `include`)
+        common = [k for k in a if a[k] is not None and b.get(k) is not None]
+        return "ids" not in a or ("ids" in common and all(_close(a[k], b[k]) for k in common))
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(_close(x, y) for x, y in zip(a, b))
+    return a == b
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_collection_equals_single_collection(tmp_path, world):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = json.load(open(tmp_path / f"sharded_{world}.json"))
+
+    single = FakeCollection(D)
+    want = json.loads(json.dumps(script(single)))           # same JSON round trip
+    assert sum(got["shard_counts"]) == want["count_after"] and max(got["shard_counts"]) - min(got["shard_counts"]) <= 50
+    for key in want:
+        assert _close(got[key], want[key]), key            # ids in the same ORDER: ties break by insertion order
+    assert got["q5"]["ids"][0][:2] == ["doc_000000000000_text_3", "doc_000000000002_text_100"]
+
+    from multimodal_rag_amd.embedder import EmbeddingManager
+
+    m = EmbeddingManager(engine=FakeEngine(D))
+    assert _close(got["manager"], json.loads(json.dumps(manager_script(m))))

@@ -1,0 +1,66 @@
+"""GPU: the serving loop's collection over a real VectorIndex shard and a real RCCL communicator (one rank on
+the one-GPU box: ncclAllGather, host merge, payload gather all run; N > 1 is covered by tests/test_serving_gloo.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield True
+    dist.destroy_process_group()
+
+
+def test_sharded_collection_over_vector_index_matches_plain_index(pg):
+    from multimodal_rag_amd.index import VectorIndex
+    from multimodal_rag_amd.serving import ShardedCollection
+
+    d, n = 384, 3000
+    g = np.random.default_rng(4)
+    v = g.standard_normal((n, d)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[2000] = v[7]
+    ids = [f"doc_{i // 1000:012x}_text_{i}" for i in range(n)]
+    metas = [{"doc_id": s[:16], "item_id": s[17:], "type": "image" if i % 5 == 0 else "text"} for i, s in enumerate(ids)]
+    docs = [f"d{i}" for i in range(n)]
+    q = g.standard_normal((17, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = v[7]
+
+    plain = VectorIndex(d, device="cuda:0")
+    col = ShardedCollection(VectorIndex(d, device="cuda:0"), device=torch.device("cuda", 0))
+    for c in (plain, col):
+        for lo in range(0, n, 1000):
+            c.add(v[lo:lo + 1000].tolist(), documents=docs[lo:lo + 1000], metadatas=metas[lo:lo + 1000], ids=ids[lo:lo + 1000])
+    assert col.count() == plain.count() == n
+    for kw in ({"n_results": 5}, {"n_results": 20, "where": {"type": "image"}}, {"n_results": 3, "where": {"doc_id": "doc_000000000001"}}):
+        a, b = col.query(q.tolist(), **kw), plain.query(q.tolist(), **kw)
+        assert a["ids"] == b["ids"] and a["documents"] == b["documents"] and a["metadatas"] == b["metadatas"]
+        assert np.array_equal(np.array(a["distances"]), np.array(b["distances"]))
+    assert col.query(q[:1].tolist(), n_results=5)["ids"][0][:2] == [ids[7], ids[2000]]     # tie: earlier insert first
+    deep_a = col.query(q[:1].tolist(), n_results=45, include=("distances",))
+    deep_b = plain.query(q[:1].tolist(), n_results=45, include=("distances",))
+    assert deep_a["ids"] == deep_b["ids"] and len(deep_a["ids"][0]) == 45
+    assert col.delete(where={"doc_id": "doc_000000000000"}) == plain.delete(where={"doc_id": "doc_000000000000"})
+    assert col.count() == plain.count() == 2000
+    assert col.query(q.tolist(), n_results=5)["ids"] == plain.query(q.tolist(), n_results=5)["ids"]
+    got = col.get(ids=[ids[2500], ids[1001]], include=("documents", "embeddings"))
+    want = plain.get(ids=[ids[2500], ids[1001]], include=("documents", "embeddings"))
+    assert got["ids"] == want["ids"] and got["documents"] == want["documents"] and got["embeddings"] == want["embeddings"]
+    col.reset()
+    assert col.count() == 0
+    col.stop()
