@@ -163,9 +163,10 @@ struct LinearParams {
     _Float16 *out;
     int M, N, K;
     int act;
+    int xcd_order;
 };
 
-template <int BF, int BT, int WF, int WT, int NSTAGE>
+template <int BF, int BT, int WF, int WT, int NSTAGE, bool PIPE = false>
 __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(const LinearParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WF * WT;
@@ -191,8 +192,17 @@ __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(cons
     const int h = lane >> 5;
 
     const int tiles_f = (p.N + BF - 1) / BF;
-    const int tile_f = blockIdx.x % tiles_f;
-    const int tile_t = blockIdx.x / tiles_f;
+    // XCD-aware order: workgroup i runs on XCD i % 8, each with its own L2.  Give every XCD a contiguous
+    // band of tiles, so the tiles_f workgroups that share an x row-tile (and run at about the same time)
+    // share one L2 instead of fetching that tile through eight.
+    int lid = blockIdx.x;
+    if (p.xcd_order) {
+        const int total = gridDim.x, per = total / 8, rem = total % 8;
+        const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+        lid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    }
+    const int tile_f = lid % tiles_f;
+    const int tile_t = lid / tiles_f;
     const int f0 = tile_f * BF;
     const int t0 = tile_t * BT;
     const unsigned RB = (unsigned)p.K * 2u;
@@ -237,6 +247,66 @@ __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(cons
 
     int issued = 0;
     for (; issued < NSTAGE - 1 && issued < nk; ++issued) issue(issued);
+    if constexpr (PIPE) {
+        // Software-pipelined form: the fragments of k-step m+1 are read while the MFMAs of step m issue,
+        // and the ring barrier sits BEFORE the last k-step's MFMAs of a slab -- those need no LDS, so
+        // they cover the barrier wake-up and the read latency of the next slab's first fragments.
+        half8_t fa[2][RF], fb[2][RT];
+        auto load = [&](half8_t(&a_)[RF], half8_t(&b_)[RT], const char *st, int m) {
+            const int off = ((2 * m + h) ^ sw) * 16;
+#pragma unroll
+            for (int b = 0; b < RT; ++b) b_[b] = *(const half8_t *)(st + b_base + b * (32 * SLAB) + off);
+#pragma unroll
+            for (int a = 0; a < RF; ++a) a_[a] = *(const half8_t *)(st + a_base + a * (32 * SLAB) + off);
+        };
+        auto mma = [&](const half8_t(&a_)[RF], const half8_t(&b_)[RT]) {
+#pragma unroll
+            for (int a = 0; a < RF; ++a)
+#pragma unroll
+                for (int b = 0; b < RT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[a], b_[b], acc[a][b], 0, 0, 0);
+        };
+        // pin the order inside a (reads of the next step, MFMAs of this step) group: one read, one MFMA, ...
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < RF + RT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, (RF * RT) / (RF + RT), 0);  // MFMA(s)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        wait_items<PW, NSTAGE - 2>(issued - 1);
+        __builtin_amdgcn_s_barrier();
+        if (issued < nk) {
+            issue(issued);
+            ++issued;
+        }
+        load(fa[0], fb[0], smem, 0);
+        for (int it = 0; it < nk; ++it) {
+            const char *st = smem + (it % NSTAGE) * STAGE;
+            load(fa[1], fb[1], st, 1);
+            mma(fa[0], fb[0]);
+            interleave();
+            load(fa[0], fb[0], st, 2);
+            mma(fa[1], fb[1]);
+            interleave();
+            load(fa[1], fb[1], st, 3);
+            mma(fa[0], fb[0]);
+            interleave();
+            if (it + 1 < nk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of this stage are complete
+                wait_items<PW, NSTAGE - 2>(issued - it - 2);
+                __builtin_amdgcn_s_barrier();
+                if (issued < nk) {
+                    issue(issued);  // into the stage every wave has just finished reading
+                    ++issued;
+                }
+                load(fa[0], fb[0], smem + ((it + 1) % NSTAGE) * STAGE, 0);
+            }
+            mma(fa[1], fb[1]);
+            interleave();
+        }
+    } else
     for (int it = 0; it < nk; ++it) {
         wait_items<PW, NSTAGE - 2>(issued - it - 1);
         __builtin_amdgcn_s_barrier();
@@ -635,11 +705,17 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
     p.resid = (const _Float16 *)resid;
     p.out = (_Float16 *)out;
     p.M = M, p.N = N, p.K = K, p.act = act;
+    p.xcd_order = getenv("MMRAG_LINEAR_PLAIN") ? 0 : 1;
     const int cus = num_cus();
     const long long big_tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
     if (big_tiles >= cus && N % 256 == 0) {
         // 16 waves (4 per SIMD): +10-20 % over 8 waves on the encoder shapes (A/B in one process)
-        linear_kernel<256, 256, 4, 4, 2><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
+        // 16 waves (4 per SIMD): +10-20 % over 8 waves on the encoder shapes; software-pipelined fragment
+        // reads + XCD-aware tile order: another +4-15 % (A/B in one process, tools/linear_vs_rocblas.py)
+        if (getenv("MMRAG_LINEAR_PLAIN"))
+            linear_kernel<256, 256, 4, 4, 2><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
+        else
+            linear_kernel<256, 256, 4, 4, 2, true><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
     } else {
         const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
         linear_kernel<128, 128, 2, 2, 3><<<(unsigned)tiles, 256, 0, s>>>(p);
