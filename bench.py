@@ -147,24 +147,31 @@ def main():
     events = {}
 
     plans = [N.SearchPlan(q, corpus, n_local, DIM, k, ws[i]) for i in range(SLOTS)]
-    main_stream = torch.cuda.current_stream(dev).cuda_stream
+    main_torch = torch.cuda.current_stream(dev)
+    main_stream = main_torch.cuda_stream
+    side_ptr = [main_stream]
 
     def local_scan(slot):       # phase 1: the fused GEMM + top-k kernel (the roofline kernel)
         ev = events.get(slot)
         if ev is not None:
-            ev[0].record()
+            ev[0].record(main_torch)
         plans[slot % SLOTS].scan(main_stream)
         if ev is not None:
-            ev[1].record()
+            ev[1].record(main_torch)
 
     def local_finish(slot, out_s, out_r):   # phase 2: per-query merge of the candidate lists (side stream)
-        plans[slot % SLOTS].select(lo, out_s.data_ptr(), out_r.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        plans[slot % SLOTS].select(lo, out_s.data_ptr(), out_r.data_ptr(), side_ptr[0])
 
     from multimodal_rag_amd.sharded import ShardedSearch
 
     ss = ShardedSearch(B, k, world, rank, dev, local_finish, merge=args.merge,
                        collective_on_host=(args.dist_backend == "gloo"), local_scan=local_scan,
                        force_exchange=force_exchange, n_slots=SLOTS)
+    # the tail stream stays current for the whole loop (scans get the main stream explicitly): no stream-context
+    # switch per batch on the host
+    side_ptr[0] = ss.side.cuda_stream
+    ss.side_is_current = True
+    torch.cuda.set_stream(ss.side)
     final = {}
 
     host_t = {"launch": 0.0, "finish": 0.0}
@@ -204,6 +211,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    torch.cuda.set_stream(main_torch)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()])) if events else float("nan")
     gpu_s = final["s"].clone().numpy()
     gpu_r = final["r"].clone().numpy()

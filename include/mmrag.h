@@ -117,6 +117,11 @@ int mmrag_gather_rows(void *dst, const void *src, int64_t ld, int dtype,
 int mmrag_fetch_rows_f32(const void *corpus, int64_t ld, int dtype, const int64_t *rows,
                          int64_t m, int d, float *out, void *stream);
 
+/* Stream-ordered copy of a result block into (pinned) host memory: the last step of a query batch
+ * (`results['ids'][0]` ... reach the host, embedder.py:604-609).  Thin wrapper so a serving loop can stay
+ * on raw stream handles. */
+int mmrag_copy_to_host_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+
 
 /* ---------------------------------------------------------------------------------------
  * Embed.  Replaces SentenceTransformer.encode(texts, batch_size=len(texts),

@@ -57,6 +57,8 @@ def _declare(lib):
     lib.mmrag_gather_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
     lib.mmrag_fetch_rows_f32.restype = c_int
     lib.mmrag_fetch_rows_f32.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]
+    lib.mmrag_copy_to_host_async.restype = c_int
+    lib.mmrag_copy_to_host_async.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mmrag_encoder_workspace_bytes.restype = c_size_t
     lib.mmrag_encoder_workspace_bytes.argtypes = [c_void_p, c_int64, c_int]
     lib.mmrag_encoder_forward.restype = c_int
@@ -433,6 +435,15 @@ def resize_crop_u8(src: torch.Tensor, bx: torch.Tensor, kx: torch.Tensor, by: to
                                         y_lo, y_hi, tmp.data_ptr(), out.data_ptr(), _stream_ptr(src.device))
     _check(st, "mmrag_resize_crop_u8")
     return out
+
+
+def copy_to_host_async(dst_host: torch.Tensor, src_dev: torch.Tensor, stream: int) -> None:
+    """Stream-ordered device -> pinned host copy on a raw hipStream_t (no torch stream context)."""
+    nbytes = src_dev.numel() * src_dev.element_size()
+    if dst_host.is_cuda or not src_dev.is_cuda or dst_host.numel() * dst_host.element_size() < nbytes:
+        raise MMRagNativeError("copy_to_host_async: need a host destination at least as large as the device source")
+    _check(lib().mmrag_copy_to_host_async(dst_host.data_ptr(), src_dev.data_ptr(), nbytes, stream),
+           "mmrag_copy_to_host_async")
 
 
 class SearchPlan:

@@ -163,4 +163,10 @@ int mmrag_fetch_rows_f32(const void *corpus, int64_t ld, int dtype, const int64_
     return MMRAG_OK;
 }
 
+int mmrag_copy_to_host_async(void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+    MMRAG_CHECK_ARG(dst_host && src_dev, "copy_to_host_async: null pointer");
+    MMRAG_CHECK_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MMRAG_OK;
+}
+
 }  // extern "C"

@@ -86,7 +86,10 @@ class ShardedSearch:
         # waits out a whole scan.
         self.side = torch.cuda.Stream(self.device, priority=-1) if (on_gpu and local_scan is not None) else None
         self.scanned = [torch.cuda.Event() for _ in range(n_slots)] if self.side is not None else None
-        self.tail_done = [torch.cuda.Event() for _ in range(n_slots)] if self.side is not None else None
+        # stream the scans run on (the one current at construction); with `side_is_current` the caller then
+        # keeps `self.side` current for the whole loop, which saves a stream-context switch per batch
+        self.main = torch.cuda.current_stream(self.device) if self.side is not None else None
+        self.side_is_current = False
         self._tail_used = [False] * n_slots
 
     def _views(self, buf: torch.Tensor):
@@ -102,16 +105,19 @@ class ShardedSearch:
         if self.side is None:
             self._tail(slot, b)
             return
-        main = torch.cuda.current_stream(self.device)
+        main = self.main
         if self._tail_used[b]:
-            main.wait_event(self.tail_done[b])   # the slot's workspace / buffers are free again
+            main.wait_event(self.copied[b])      # the slot's workspace / buffers are free again
         self.local_scan(slot)
         self.scanned[b].record(main)
-        with torch.cuda.stream(self.side):
+        if self.side_is_current:                 # caller made the side stream current for the whole loop
             self.side.wait_event(self.scanned[b])
             self._tail(slot, b)
-            self.tail_done[b].record(self.side)
-            self._tail_used[b] = True
+        else:
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.scanned[b])
+                self._tail(slot, b)
+        self._tail_used[b] = True
 
     def _tail(self, slot: int, b: int):
         loc, all_ = self.locs[b], self.alls[b]
@@ -127,10 +133,12 @@ class ShardedSearch:
             nb = self.B * self.k
             self.host[b][nb * 8: nb * 12].view(torch.float32).view(self.B, self.k).copy_(s, non_blocking=True)
             self.host[b][: nb * 8].view(torch.int64).view(self.B, self.k).copy_(r, non_blocking=True)
+        elif self.side is not None:
+            _native.copy_to_host_async(self.host[b], all_, self.side.cuda_stream)
         else:
             self.host[b].copy_(all_, non_blocking=True)
         if self.copied is not None:
-            self.copied[b].record()
+            self.copied[b].record(self.side) if self.side is not None else self.copied[b].record()
 
     def finish(self, slot: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Host phase: wait for the batch's copy, merge G*k -> k per query.  Returns CPU tensors."""
