@@ -127,6 +127,8 @@ struct KParams {
     int n_tiles;
     int n_lists;          // list slots per query in cand_* (>= gridDim.x)
     int tile0;            // first corpus tile of this launch (sample pre-pass / main pass split)
+    int walkers;          // workgroups that walk the tiles, per query group (grid = walkers * query groups)
+    int share_l2;         // > 1 query group: corpus slabs are re-read by the sibling groups, keep them in L2
     const float *thr0;    // optional [B]: a known lower bound of each query's final k-th score
 };
 
@@ -157,8 +159,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
 
     const unsigned RB = p.row_bytes;
     const int nk = (int)(RB / SLAB);
-    const int q0 = blockIdx.y * QROWS;
-    const int my_tiles = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // 1-D grid of walkers * query_groups workgroups, query group major: the query groups of one walker sit
+    // walkers (a multiple of 8) ids apart, i.e. on the SAME XCD, and stream the same corpus tiles at about
+    // the same time -- one HBM fetch, the other groups hit that XCD's L2 (batches above 256 queries)
+    const int walkers = p.walkers;
+    const int bx = (int)blockIdx.x % walkers;
+    const int by = (int)blockIdx.x / walkers;
+    const int q0 = by * QROWS;
+    const int my_tiles = (p.n_tiles - bx + walkers - 1) / walkers;
     const int n_items = my_tiles * nk;
 
     // ---- DMA descriptors ------------------------------------------------------------------
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
 
     int is_tile = 0, is_k = 0;  // issue cursor: (index among my tiles, k slab)
     auto issue = [&](int stage_idx) {
-        const long long tile = (long long)p.tile0 + blockIdx.x + (long long)is_tile * gridDim.x;
+        const long long tile = (long long)p.tile0 + bx + (long long)is_tile * walkers;
         const long long row0 = tile * TM;
         const long long rows_left = p.n - row0;
         const unsigned c_bytes = (unsigned)((rows_left < TM ? rows_left : (long long)TM) * (long long)RB);
@@ -195,10 +203,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
         const unsigned koff = (unsigned)is_k * SLAB;
         // corpus rows are read exactly once, by this CU only: non-temporal (aux = 2) keeps them from
         // displacing the query slab that every workgroup re-reads from L2 (A/B: -2 % at B=256, -5 % at B<=128)
+        if (p.share_l2) {
 #pragma unroll
-        for (int i = 0; i < CLOADS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + (wave * CLOADS + i) * 1024), 16,
-                                                     c_off[i] + koff, 0, 0, 2);
+            for (int i = 0; i < CLOADS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + (wave * CLOADS + i) * 1024), 16,
+                                                         c_off[i] + koff, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CLOADS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + (wave * CLOADS + i) * 1024), 16,
+                                                         c_off[i] + koff, 0, 0, 2);
+        }
 #pragma unroll
         for (int i = 0; i < QLOADS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
     // ---- accumulators, lists ---------------------------------------------------------------
     f32x16_t acc[RM];
     auto init_acc = [&](int tile_idx) {
-        const long long tile = (long long)p.tile0 + blockIdx.x + (long long)tile_idx * gridDim.x;
+        const long long tile = (long long)p.tile0 + bx + (long long)tile_idx * walkers;
         const long long row0 = tile * TM + (long long)wm * (RM * 32);
         const bool ragged = row0 + RM * 32 > p.n;
         if (!ragged && p.alive_bits == nullptr) {
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
         if (++ks == nk) {
             // ---- epilogue: lane-local top-K over this wave's 32*RM rows of the tile ----------
             ks = 0;
-            const long long tile = (long long)p.tile0 + blockIdx.x + (long long)tile_idx * gridDim.x;
+            const long long tile = (long long)p.tile0 + bx + (long long)tile_idx * walkers;
             const int row_base = (int)(tile * TM) + wm * (RM * 32) + 4 * h;
             if constexpr (K > 5) {
                 // deep lists: one (not unrolled) insertion body per 4-row group keeps the code small
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
                     m.insert_ordered(x, xr);
                 }
             }
-            const size_t base = ((size_t)(q0 + t) * p.n_lists + blockIdx.x) * K;
+            const size_t base = ((size_t)(q0 + t) * p.n_lists + bx) * K;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 p.cand_s[base + i] = m.v[i];
@@ -557,6 +572,11 @@ Plan make_plan(int B, long long n, int k) {
     pl.n_tiles = (int)((n + TM - 1) / TM);
     const int cus = num_cus();
     pl.grid_x = pl.n_tiles < cus ? pl.n_tiles : cus;
+    if (pl.grid_y > 1 && pl.n_tiles >= cus) {
+        // all query groups of a tile resident together: cus / grid_y walkers, rounded to whole XCD rounds
+        int w = cus / pl.grid_y / 8 * 8;
+        pl.grid_x = w >= 8 ? w : (cus / pl.grid_y > 0 ? cus / pl.grid_y : 1);
+    }
     if (pl.grid_x < 1) pl.grid_x = 1;
     pl.NW = (pl.K == 5 && pl.WN == 8 && !getenv("MMRAG_NW8")) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
     // Sample pre-pass (256-query shape, and every shape with deep lists: there the epilogue, not HBM, is
@@ -572,7 +592,10 @@ Plan make_plan(int B, long long n, int k) {
 
 template <int DT, int WN, int K, int NSTAGE, int NW = 8, bool SEEDED = false>
 void launch_main(const KParams &p, dim3 grid, hipStream_t s) {
-    cosine_topk_kernel<DT, WN, K, NSTAGE, NW, SEEDED><<<grid, 64 * NW, 0, s>>>(p);
+    KParams kp = p;
+    kp.walkers = (int)grid.x;
+    kp.share_l2 = grid.y > 1;
+    cosine_topk_kernel<DT, WN, K, NSTAGE, NW, SEEDED><<<grid.x * grid.y, 64 * NW, 0, s>>>(kp);
 }
 
 // deep lists (K = 10, 20): 8 waves (2 per SIMD, 256 registers each) hold the lists next to the accumulators

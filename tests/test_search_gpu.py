@@ -97,6 +97,14 @@ def test_deep_lists_large_batches(N, B, n, d, k):
     check(*run(N, q, c, k, torch.float16))
 
 
+@pytest.mark.parametrize("B,n,d,k", [(520, 70_000, 128, 5), (1024, 200_000, 64, 5), (700, 200_000, 64, 10)])
+def test_batches_above_256_share_corpus_tiles(N, B, n, d, k):
+    """several query groups per corpus tile (co-scheduled on one XCD); the two big cases take the pre-pass"""
+    q = unit_rows(B, d, 21)
+    c = unit_rows(n, d, 22)
+    check(*run(N, q, c, k, torch.float16))
+
+
 def test_deep_lists_exact_integers(N):
     g = np.random.default_rng(6)
     n, d, B = 210_000, 64, 160
