@@ -503,7 +503,9 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
                                                           long long inner, long long outer_stride,
                                                           long long q_stride, int k_out,
                                                           long long row_offset, float *__restrict__ out_s,
-                                                          long long *__restrict__ out_r) {
+                                                          long long *__restrict__ out_r,
+                                                          float *__restrict__ thr0, float *__restrict__ seed_s,
+                                                          int *__restrict__ seed_r, long long seed_q_stride) {
     __shared__ float sh_v[4 * K];
     __shared__ long long sh_r[4 * K];
     const int q = blockIdx.x;
@@ -543,6 +545,19 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
                     const bool valid = orr[i] != LLONG_MAX && ov[i] > NEG_INF;
                     out_s[(size_t)q * k_out + i] = valid ? ov[i] : NEG_INF;
                     out_r[(size_t)q * k_out + i] = valid ? orr[i] + row_offset : -1;
+                }
+            }
+            if (thr0 != nullptr) {
+                // sample pre-pass: thr0[q] = k-th score of the sample's exact top-K (a valid lower bound of the
+                // final k-th score; -inf when the sample held fewer than K live rows), and the sample's top-K
+                // becomes one more candidate list of the final merge (seed_* points at that list slot)
+                const bool full = orr[K - 1] != LLONG_MAX && ov[K - 1] > NEG_INF;
+                thr0[q] = full ? ov[K - 1] : NEG_INF;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const bool valid = orr[i] != LLONG_MAX && ov[i] > NEG_INF;
+                    seed_s[(size_t)q * seed_q_stride + i] = valid ? ov[i] : NEG_INF;
+                    seed_r[(size_t)q * seed_q_stride + i] = valid ? (int)orr[i] : INT_MAX;
                 }
             }
         }
@@ -628,35 +643,18 @@ int dispatch_main(const Plan &pl, const KParams &p, hipStream_t s) {
 template <typename RowT>
 int launch_merge(int K, const float *cs, const RowT *cr, long long n_cand, long long inner,
                  long long outer_stride, long long q_stride, int B, int k_out, long long row_offset,
-                 float *out_s, long long *out_r, hipStream_t s) {
+                 float *out_s, long long *out_r, hipStream_t s, float *thr0 = nullptr, float *seed_s = nullptr,
+                 int *seed_r = nullptr, long long seed_q_stride = 0) {
     if (K == 5)
         merge_topk_kernel<5, RowT><<<B, 256, 0, s>>>(cs, cr, n_cand, inner, outer_stride, q_stride, k_out,
-                                                     row_offset, out_s, out_r);
+                                                     row_offset, out_s, out_r, thr0, seed_s, seed_r, seed_q_stride);
     else if (K == 10)
         merge_topk_kernel<10, RowT><<<B, 256, 0, s>>>(cs, cr, n_cand, inner, outer_stride, q_stride, k_out,
-                                                      row_offset, out_s, out_r);
+                                                      row_offset, out_s, out_r, thr0, seed_s, seed_r, seed_q_stride);
     else
         merge_topk_kernel<20, RowT><<<B, 256, 0, s>>>(cs, cr, n_cand, inner, outer_stride, q_stride, k_out,
-                                                      row_offset, out_s, out_r);
+                                                      row_offset, out_s, out_r, thr0, seed_s, seed_r, seed_q_stride);
     return MMRAG_OK;
-}
-
-// after the sample pre-pass: thr0[q] = k-th score of the sample's exact top-K (a valid lower bound of
-// the final k-th score), and the sample's top-K becomes one more candidate list of the final merge
-template <int K>
-__global__ void seed_kernel(const float *__restrict__ top_s, const long long *__restrict__ top_r, int B,
-                            float *__restrict__ thr0, float *__restrict__ cand_s, int *__restrict__ cand_r,
-                            int n_lists, int slot) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= B) return;
-    thr0[q] = top_s[(size_t)q * K + K - 1];  // -inf when the sample held fewer than K live rows
-    const size_t base = ((size_t)q * n_lists + slot) * K;
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const long long r = top_r[(size_t)q * K + i];
-        cand_s[base + i] = top_s[(size_t)q * K + i];
-        cand_r[base + i] = r < 0 ? INT_MAX : (int)r;
-    }
 }
 
 __global__ void fill_empty_kernel(float *s, long long *r, long long total) {
@@ -756,12 +754,9 @@ int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n,
         MMRAG_CHECK_HIP(hipGetLastError());
         // 2. its exact top-K per query, 3. seed thresholds + keep it as the last candidate list
         const long long n_cand = (long long)pre.grid_x * pl.K;
+        const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the last list slot of every query
         launch_merge<int>(pl.K, p.cand_s, p.cand_r, n_cand, n_cand, 0, (long long)pl.n_lists * pl.K, B, pl.K, 0, top_s,
-                          top_r, s);
-        const unsigned sg = (unsigned)((B + 255) / 256);
-        if (pl.K == 5) seed_kernel<5><<<sg, 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r, pl.n_lists, pl.n_lists - 1);
-        else if (pl.K == 10) seed_kernel<10><<<sg, 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r, pl.n_lists, pl.n_lists - 1);
-        else seed_kernel<20><<<sg, 256, 0, s>>>(top_s, top_r, B, thr0, p.cand_s, p.cand_r, pl.n_lists, pl.n_lists - 1);
+                          top_r, s, thr0, p.cand_s + seed_off, p.cand_r + seed_off, (long long)pl.n_lists * pl.K);
         MMRAG_CHECK_HIP(hipGetLastError());
         // 4. main pass over the remaining tiles, selection armed with the sample thresholds
         Plan mainp = pl;
