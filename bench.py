@@ -256,7 +256,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "cosine_topk_kernel",
-                "launch": "one scan = sample pre-pass + main pass of cosine_topk_kernel (+ merge_topk/seed between)",
+                "launch": "one scan = sample pre-pass + main pass of cosine_topk_kernel (+ merge_topk between, which also seeds the thresholds)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(kern_ms, 4),
