@@ -381,8 +381,8 @@ __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(cons
 // qkv is [T, 3H] fp16 (Q | K | V column blocks).  One workgroup = (128-query tile, head, seq),
 // 4 waves x 32 queries; keys are consumed in tiles of 64.
 // ---------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(256, 1) void attention_kernel(const _Float16 *__restrict__ qkv,
+template <int DH, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__restrict__ qkv,
                                                             const int *__restrict__ cu_seqlens,
                                                             _Float16 *__restrict__ ctx, int H, float scale,
                                                             int causal) {
@@ -776,12 +776,14 @@ int mmrag_attention_f16(const void *qkv, const int32_t *cu_seqlens, void *ctx, i
     MMRAG_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 8) == 0, "attention: misaligned pointer");
     const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)n_heads, (unsigned)B);
     const float scale = 1.0f / sqrtf((float)dh);
+    // 3 waves per SIMD (<= 168 registers): -25 % vs the unconstrained 194-register build, which only fits 2
+    // (A/B in one process, tools/attn_bench.py; 4 per SIMD spills and is slower)
     if (dh == 64)
-        attention_kernel<64><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens, (_Float16 *)ctx,
-                                                                    H, scale, causal);
+        attention_kernel<64, 3><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
+                                                                       (_Float16 *)ctx, H, scale, causal);
     else
-        attention_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens, (_Float16 *)ctx,
-                                                                    H, scale, causal);
+        attention_kernel<32, 3><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
+                                                                       (_Float16 *)ctx, H, scale, causal);
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;
 }
