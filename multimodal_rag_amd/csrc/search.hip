@@ -25,6 +25,7 @@
 //   * every lane list is written once at kernel end; a second tiny kernel merges the
 //     gridDim.x * WM * 2 lists per query into the final [B, k] (ties -> lower row).
 #include "mmrag_internal.h"
+#include "tile_dma.h"
 
 #include <limits.h>
 #include <stdlib.h>
@@ -33,14 +34,7 @@ using namespace mmrag;
 
 namespace mmrag_impl {
 
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-
 constexpr int TM = 256;            // corpus rows per tile
-constexpr int SLAB = 128;          // bytes of K per row per stage
 constexpr int CORPUS_STAGE = TM * SLAB;  // 32 KiB
 constexpr float NEG_INF = -__builtin_inff();
 
@@ -91,29 +85,6 @@ struct TopList {
     }
 };
 
-
-template <int N>
-__device__ inline void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// wait until at most `items` later ring items (LOADS wave-instructions each) are outstanding
-template <int LOADS, int MAXITEMS>
-__device__ inline void wait_items(int items) {
-    if constexpr (MAXITEMS >= 2) {
-        if (items >= 2) {
-            wait_vmcnt<2 * LOADS>();
-            return;
-        }
-    }
-    if constexpr (MAXITEMS >= 1) {
-        if (items >= 1) {
-            wait_vmcnt<LOADS>();
-            return;
-        }
-    }
-    wait_vmcnt<0>();
-}
 
 struct KParams {
     const char *q;        // [B, ld]

@@ -69,61 +69,4 @@ __device__ inline void dma_piece(__amdgpu_buffer_rsrc_t rsrc, char *lds_tile, in
 __device__ inline int frag_offset(int row, int chunk) { return row * SLAB + ((chunk ^ ((row >> 1) & 7)) * 16); }
 
 
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-
-// ---- hand-placed LDS fragment reads -------------------------------------------------------
-// hipcc sinks every ds_read_b128 next to the MFMA that consumes it (one lgkmcnt(0) per MFMA:
-// the matrix pipe idles for a full LDS latency each time).  These helpers issue a whole
-// k-slice of fragments as opaque asm and tie the destinations to ONE later wait, so the reads
-// of slice m+1 fly while the MFMAs of slice m issue (cdna_hip_programming.md section 5.7,
-// form (ii): "=v" loads, then a wait statement naming every destination "+v").
-template <int R>
-struct FragSet {
-    i32x4_t a[R];  // R row blocks of the register-side operand
-    i32x4_t b;     // the lane-side operand
-};
-
-__device__ inline unsigned lds_addr(const void *p) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-template <int R, int ROW_BLOCK_BYTES>
-__device__ inline void frag_issue(FragSet<R> &f, unsigned a_addr, unsigned b_addr) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(f.b) : "v"(b_addr));
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[i]) : "v"(a_addr), "n"(i * ROW_BLOCK_BYTES));
-}
-
-template <int R>
-__device__ inline void frag_wait(FragSet<R> &f) {
-    static_assert(R == 1 || R == 2 || R == 4 || R == 8, "R");
-    if constexpr (R == 1)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b), "+v"(f.a[0]));
-    else if constexpr (R == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b), "+v"(f.a[0]), "+v"(f.a[1]));
-    else if constexpr (R == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(f.b), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.a[4]), "+v"(f.a[5]),
-                       "+v"(f.a[6]), "+v"(f.a[7]));
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// keep a fragment set's registers allocated up to this point (so the next slice's reads cannot
-// be placed in registers an in-flight MFMA is still sourcing)
-template <int R>
-__device__ inline void frag_keep(const FragSet<R> &f) {
-    if constexpr (R == 1)
-        asm volatile("" ::"v"(f.b), "v"(f.a[0]));
-    else if constexpr (R == 2)
-        asm volatile("" ::"v"(f.b), "v"(f.a[0]), "v"(f.a[1]));
-    else if constexpr (R == 4)
-        asm volatile("" ::"v"(f.b), "v"(f.a[0]), "v"(f.a[1]), "v"(f.a[2]), "v"(f.a[3]));
-    else
-        asm volatile("" ::"v"(f.b), "v"(f.a[0]), "v"(f.a[1]), "v"(f.a[2]), "v"(f.a[3]), "v"(f.a[4]), "v"(f.a[5]),
-                     "v"(f.a[6]), "v"(f.a[7]));
-}
-
 }  // namespace mmrag_impl
