@@ -20,6 +20,8 @@
 #include "mmrag_internal.h"
 #include "tile_dma.h"
 
+#include <type_traits>
+
 #include <limits.h>
 #include <stdlib.h>
 
@@ -43,9 +45,21 @@ __device__ inline float wave_sum(float v) {
     return v;
 }
 
-__device__ inline float act_apply(float x, int act) {
-    if (act == MMRAG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    if (act == MMRAG_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+template <int ACT>
+__device__ inline float act_apply(float x) {
+    if constexpr (ACT == MMRAG_ACT_GELU) {
+        // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output step): one rcp, one
+        // exp2 and six fma instead of libm's branchy erff, which cost 12 us per 256x256 tile -- more than
+        // half of the K=768 main loop
+        const float z = fabsf(x) * 0.70710678118654752f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+        const float poly =
+            t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+        const float erf_abs = fmaf(-poly, e, 1.0f);
+        return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    }
+    if constexpr (ACT == MMRAG_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
     return x;
 }
 
@@ -331,46 +345,98 @@ __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(cons
         }
     }
 
-    // ---- epilogue phase 1: bias + activation in fp32, stage the tile as [token][feature] fp16
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+    // ---- epilogue ---------------------------------------------------------------------------
+    // residual rows are fetched FIRST (their latency hides under phase 1), 16 bytes per lane
+    constexpr int LPR = BF / 8;              // lanes per output row
+    constexpr int RPI = 64 / LPR;            // rows per wave instruction
+    constexpr int ITERS = BT / (NW * RPI);
+    static_assert(BT % (NW * RPI) == 0, "row split");
+    const int sub = lane / LPR;
+    const int col = (lane % LPR) * 8;
+    const bool wide = (p.N & 7) == 0;        // 16-byte rows possible (always for the encoder shapes)
+    half8_t rv[ITERS];
+    if (wide && p.resid != nullptr) {
 #pragma unroll
-    for (int a = 0; a < RF; ++a) {
-        const int fl = wf * RF * 32 + a * 32 + 4 * h;  // local feature of register group 0
+        for (int i = 0; i < ITERS; ++i) {
+            const int t = t0 + wave * RPI + sub + i * NW * RPI;
+            const int f = f0 + col;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f = fl + 8 * g;  // features f .. f+3 live in registers 4g .. 4g+3
-            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr && f0 + f + 3 < p.N) {
-                const float4 bv = *(const float4 *)(p.bias + f0 + f);
-                bias4[0] = bv.x, bias4[1] = bv.y, bias4[2] = bv.z, bias4[3] = bv.w;
-            }
-#pragma unroll
-            for (int b = 0; b < RT; ++b) {
-                const int tl = wt_ * RT * 32 + b * 32 + r32;
-                half4_t o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply(acc[a][b][4 * g + i] + bias4[i], p.act);
-                *(half4_t *)(smem + tl * STG_ROW + f * 2) = o;
-            }
+            for (int e = 0; e < 8; ++e) rv[i][e] = (_Float16)0.f;
+            if (t < p.M && f < p.N) rv[i] = *(const half8_t *)(p.resid + (size_t)t * p.N + f);
         }
     }
-    __syncthreads();
-    // ---- phase 2: whole-row stores (8 bytes per lane, BF*2 contiguous bytes per row)
-    constexpr int LANES_PER_ROW = BF / 4;
-    constexpr int ROWS_PER_INSTR = 64 / LANES_PER_ROW;
-    const int sub = lane / LANES_PER_ROW;
-    const int col = (lane % LANES_PER_ROW) * 4;
-    for (int r = wave * ROWS_PER_INSTR + sub; r < BT; r += NW * ROWS_PER_INSTR) {
-        const int t = t0 + r;
-        const int f = f0 + col;
-        if (t < p.M && f < p.N) {
-            half4_t v = *(const half4_t *)(smem + r * STG_ROW + col * 2);
-            if (p.resid != nullptr) {
-                const half4_t rv = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+    // phase 1: bias + activation in fp32, stage the tile as [token][feature] fp16
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+    // (the activation is a compile-time constant inside the unrolled loops: a run-time test per element
+    // cost more than the arithmetic)
+    auto stage = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (_Float16)((float)v[i] + (float)rv[i]);
+        for (int a = 0; a < RF; ++a) {
+            const int fl = wf * RF * 32 + a * 32 + 4 * h;  // local feature of register group 0
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = fl + 8 * g;  // features f .. f+3 live in registers 4g .. 4g+3
+                float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias != nullptr && f0 + f + 3 < p.N) {
+                    const float4 bv = *(const float4 *)(p.bias + f0 + f);
+                    bias4[0] = bv.x, bias4[1] = bv.y, bias4[2] = bv.z, bias4[3] = bv.w;
+                }
+#pragma unroll
+                for (int b = 0; b < RT; ++b) {
+                    const int tl = wt_ * RT * 32 + b * 32 + r32;
+                    half4_t o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply<ACT>(acc[a][b][4 * g + i] + bias4[i]);
+                    *(half4_t *)(smem + tl * STG_ROW + f * 2) = o;
+                }
             }
-            *(half4_t *)(p.out + (size_t)t * p.N + f) = v;
+        }
+    };
+    if (p.act == MMRAG_ACT_GELU) stage(std::integral_constant<int, MMRAG_ACT_GELU>{});
+    else if (p.act == MMRAG_ACT_QUICK_GELU) stage(std::integral_constant<int, MMRAG_ACT_QUICK_GELU>{});
+    else stage(std::integral_constant<int, MMRAG_ACT_NONE>{});
+    __syncthreads();
+    // phase 2: whole-row stores
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int r = wave * RPI + sub + i * NW * RPI;
+            const int t = t0 + r;
+            const int f = f0 + col;
+            if (t < p.M && f < p.N) {
+                const half4_t lo = *(const half4_t *)(smem + r * STG_ROW + col * 2);
+                const half4_t hi = *(const half4_t *)(smem + r * STG_ROW + col * 2 + 8);
+                half8_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = lo[e];
+                    v[4 + e] = hi[e];
+                }
+                if (p.resid != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[i][e]);
+                }
+                *(half8_t *)(p.out + (size_t)t * p.N + f) = v;
+            }
+        }
+    } else {
+        constexpr int LANES_PER_ROW = BF / 4;  // 8 bytes per lane
+        constexpr int ROWS_PER_INSTR = 64 / LANES_PER_ROW;
+        const int sub4 = lane / LANES_PER_ROW;
+        const int col4 = (lane % LANES_PER_ROW) * 4;
+        for (int r = wave * ROWS_PER_INSTR + sub4; r < BT; r += NW * ROWS_PER_INSTR) {
+            const int t = t0 + r;
+            const int f = f0 + col4;
+            if (t < p.M && f < p.N) {
+                half4_t v = *(const half4_t *)(smem + r * STG_ROW + col4 * 2);
+                if (p.resid != nullptr) {
+                    const half4_t rv4 = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (_Float16)((float)v[e] + (float)rv4[e]);
+                }
+                *(half4_t *)(p.out + (size_t)t * p.N + f) = v;
+            }
         }
     }
 #endif
