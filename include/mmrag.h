@@ -185,6 +185,18 @@ int mmrag_vit_forward(const mmrag_encoder_desc *desc, const void *const *w, cons
                       const int32_t *cu_seqlens, int B, float *out, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* Host-side WordPiece tokenizer (multi-threaded).  Replaces the tokenisation SentenceTransformer.encode performs
+ * in native code (Hugging Face `tokenizers`) before the model runs -- app/utils/embedder.py:397-403.  BERT uncased
+ * BasicTokenizer + greedy longest-match WordPiece over a caller-supplied vocabulary; strings travel as UTF-32.
+ *   create   vocab token i = cps[offsets[i] .. offsets[i+1]), id = i; [CLS]/[SEP]/[UNK] looked up by name
+ *            (defaults 101/102/100).  Returns NULL on error.
+ *   encode   text i = cps[offsets[i] .. offsets[i+1]); ids [n, max_length] int32: row i holds
+ *            [CLS] pieces... [SEP] truncated to max_length, lens[i] its length; n_threads host threads. */
+void *mmrag_wordpiece_create(const uint32_t *cps, const int64_t *offsets, int n_tokens, int lower);
+void mmrag_wordpiece_destroy(void *tokenizer);
+int mmrag_wordpiece_encode_batch(const void *tokenizer, const uint32_t *cps, const int64_t *offsets, int n,
+                                 int max_length, int32_t *ids, int32_t *lens, int n_threads);
+
 /* Image front end of the vision tower (BASELINE config 4; the reference has no image encoder):
  * CLIP's preprocessing = shortest edge -> 224 with PIL bicubic, centre crop, done on uint8.  Bit-exact with
  * Pillow's 8-bit resampler (two integer passes, 22-bit fixed-point taps).

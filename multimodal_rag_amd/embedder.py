@@ -79,7 +79,7 @@ class HipEngine:
 
         from . import _native
         from .encoder import PRESETS, DeviceEncoder
-        from .tokenizer import HashTokenizer, WordPieceTokenizer
+        from .tokenizer import HashTokenizer, NativeWordPieceTokenizer
 
         _native.lib()
         if not torch.cuda.is_available():
@@ -92,7 +92,7 @@ class HipEngine:
         if model_dir:
             self.encoder = DeviceEncoder.from_local_dir(model_dir, self.device)
             vocab = os.path.join(model_dir, "vocab.txt")
-            self.tokenizer = (WordPieceTokenizer.from_vocab_file(vocab) if os.path.exists(vocab)
+            self.tokenizer = (NativeWordPieceTokenizer.from_vocab_file(vocab) if os.path.exists(vocab)
                               else HashTokenizer(self.encoder.cfg.vocab))
         else:
             if model_name not in PRESETS:
@@ -106,8 +106,10 @@ class HipEngine:
         self._torch = torch
 
     def encode(self, texts: List[str]) -> np.ndarray:
-        seqs = [self.tokenizer.encode(t, self.max_seq_length) for t in texts]
-        out = self.encoder.encode_ids(seqs)
+        if hasattr(self.tokenizer, "encode_batch_arrays"):   # native, multi-threaded tokenizer
+            out = self.encoder.encode_id_rows(*self.tokenizer.encode_batch_arrays(texts, self.max_seq_length))
+        else:
+            out = self.encoder.encode_ids([self.tokenizer.encode(t, self.max_seq_length) for t in texts])
         return out.cpu().numpy()
 
     def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):

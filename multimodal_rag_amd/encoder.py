@@ -188,6 +188,24 @@ class DeviceEncoder:
         cu_t = torch.from_numpy(cu).to(d, non_blocking=True)
         return self.forward_packed(ids_t, pos_t, cu_t, max_len)
 
+    def encode_id_rows(self, ids2d: np.ndarray, lens: np.ndarray) -> torch.Tensor:
+        """Array form of `encode_ids` (what the native tokenizer returns): row i of `ids2d` [B, W] int32 holds
+        lens[i] token ids.  Packs with numpy only -- no per-sequence Python objects."""
+        L = min(self.cfg.max_seq_length, self.cfg.max_pos)
+        lens = np.minimum(np.asarray(lens, dtype=np.int32), L)
+        if lens.size == 0 or lens.min() <= 0:
+            raise ValueError("empty token sequence")
+        W = ids2d.shape[1]
+        keep = np.arange(W, dtype=np.int32)[None, :] < lens[:, None]
+        ids = np.ascontiguousarray(ids2d[keep], dtype=np.int32)
+        pos = np.broadcast_to(np.arange(W, dtype=np.int32)[None, :], ids2d.shape)[keep]
+        cu = np.zeros(len(lens) + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        d = self.device
+        return self.forward_packed(torch.from_numpy(ids).to(d, non_blocking=True),
+                                   torch.from_numpy(np.ascontiguousarray(pos)).to(d, non_blocking=True),
+                                   torch.from_numpy(cu).to(d, non_blocking=True), int(lens.max()))
+
     def forward_packed(self, ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         T, B = ids.numel(), cu_seqlens.numel() - 1

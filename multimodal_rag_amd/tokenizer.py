@@ -104,6 +104,86 @@ class WordPieceTokenizer:
         return ids[: max_length - 1] + [self.sep]
 
 
+def _utf32(strings):
+    """(codepoints uint32 [total], offsets int64 [n+1]) of a list of str (lone surrogates pass through)."""
+    import numpy as np
+
+    blobs = [s.encode("utf-32-le", "surrogatepass") for s in strings]
+    offsets = np.zeros(len(blobs) + 1, np.int64)
+    np.cumsum([len(b) // 4 for b in blobs], out=offsets[1:])
+    cps = np.frombuffer(b"".join(blobs), dtype=np.uint32) if blobs else np.zeros(0, np.uint32)
+    return np.ascontiguousarray(cps), offsets
+
+
+class NativeWordPieceTokenizer:
+    """The same tokenisation as `WordPieceTokenizer`, done by libmmrag.so's multi-threaded C++ routine
+    (csrc/tokenizer.cpp): ingest needs tens of thousands of chunks per second, the Python loop gives ~500 per
+    core.  Host-only: works without a GPU.  `encode` keeps the single-text interface; `encode_batch` is the one to
+    use in front of the encoder."""
+
+    def __init__(self, vocab: Dict[str, int], lower: bool = True, n_threads: int = 0):
+        import os
+
+        import numpy as np
+
+        from . import _native
+
+        self._lib = _native.lib()
+        n = max(vocab.values()) + 1
+        tokens = [""] * n
+        for t, i in vocab.items():           # position = id; a gap stays an empty (never matched) entry
+            tokens[i] = t
+        if len(vocab) != n:
+            raise ValueError("vocabulary ids must be 0..n-1 without gaps")
+        cps, offs = _utf32(tokens)
+        self._h = self._lib.mmrag_wordpiece_create(cps.ctypes.data, offs.ctypes.data, n, int(lower))
+        if not self._h:
+            raise RuntimeError(self._lib.mmrag_last_error().decode())
+        self.vocab_size = n
+        self.cls = vocab.get("[CLS]", CLS)
+        self.sep = vocab.get("[SEP]", SEP)
+        self.n_threads = n_threads or min(32, os.cpu_count() or 1)
+        self._np = np
+
+    @classmethod
+    def from_vocab_file(cls, path: str, lower: bool = True, n_threads: int = 0) -> "NativeWordPieceTokenizer":
+        with open(path, encoding="utf-8") as f:
+            vocab = {line.rstrip("\n"): i for i, line in enumerate(f)}
+        return cls(vocab, lower, n_threads)
+
+    def encode_batch_arrays(self, texts: List[str], max_length: int):
+        """(ids [n, max_length] int32, lens [n] int32): rows are [CLS] ... [SEP]; entries past lens[i] are
+        unspecified.  The form `DeviceEncoder.encode_id_rows` takes."""
+        np = self._np
+        cps, offs = _utf32(texts)
+        ids = np.empty((len(texts), max_length), np.int32)
+        lens = np.empty(len(texts), np.int32)
+        st = self._lib.mmrag_wordpiece_encode_batch(self._h, cps.ctypes.data, offs.ctypes.data, len(texts), max_length,
+                                                    ids.ctypes.data, lens.ctypes.data, self.n_threads)
+        if st:
+            raise RuntimeError(self._lib.mmrag_last_error().decode())
+        return ids, lens
+
+    def encode_batch(self, texts: List[str], max_length: int) -> List[List[int]]:
+        np = self._np
+        cps, offs = _utf32(texts)
+        ids = np.empty((len(texts), max_length), np.int32)
+        lens = np.empty(len(texts), np.int32)
+        st = self._lib.mmrag_wordpiece_encode_batch(self._h, cps.ctypes.data, offs.ctypes.data, len(texts), max_length,
+                                                    ids.ctypes.data, lens.ctypes.data, self.n_threads)
+        if st:
+            raise RuntimeError(self._lib.mmrag_last_error().decode())
+        return [ids[i, : lens[i]].tolist() for i in range(len(texts))]
+
+    def encode(self, text: str, max_length: int) -> List[int]:
+        return self.encode_batch([text], max_length)[0]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mmrag_wordpiece_destroy(h)
+
+
 class HashTokenizer:
     """STAND-IN tokenizer (no trained vocabulary available offline): BERT basic tokenisation, then
     each word maps to id 1000 + md5(word) mod (vocab - 1000).  [CLS]=101, [SEP]=102."""

@@ -78,3 +78,60 @@ def test_clip_bpe_shape_rules():
     assert len(ids) == 77 and ids[0] == tk.sot and ids[-1] == tk.eot
     assert tk.encode("") == [tk.sot, tk.eot]
     assert tk.eot == max(tk.vocab.values())  # EOS pooling picks argmax(id): the end token must be the largest id
+
+
+# ---- native (C++) WordPiece: must equal the Python restatement, which is pinned to transformers above ---------
+def _native_pair(extra=()):
+    from multimodal_rag_amd.tokenizer import NativeWordPieceTokenizer
+
+    vocab = {w: i for i, w in enumerate(VOCAB + [e for e in extra if e not in VOCAB])}
+    return WordPieceTokenizer(vocab), NativeWordPieceTokenizer(vocab, n_threads=3)
+
+
+def test_native_wordpiece_matches_transformers(tmp_path):
+    transformers = pytest.importorskip("transformers")
+    from multimodal_rag_amd.tokenizer import NativeWordPieceTokenizer
+
+    p = tmp_path / "vocab.txt"
+    p.write_text("\n".join(VOCAB) + "\n", encoding="utf-8")
+    ref = transformers.BertTokenizer(str(p), do_lower_case=True)
+    nat = NativeWordPieceTokenizer.from_vocab_file(str(p))
+    assert nat.encode_batch(TEXTS, 32) == [ref(t, truncation=True, max_length=32)["input_ids"] for t in TEXTS]
+    long = "the quick brown fox " * 50
+    assert nat.encode(long, 16) == ref(long, truncation=True, max_length=16)["input_ids"]
+
+
+def test_native_wordpiece_fuzz_against_python():
+    """Unicode corner cases: final sigma, dotted capital I, Hangul and compatibility-ideograph decomposition, stacked
+    combining marks (canonical reordering), every whitespace / control class, lone surrogates, astral planes."""
+    import random
+
+    extra = ["σ", "ς", "##σ", "ας", "i̇", "ᄀ", "ᅡ", "##ᅡ", "e", "##e", "́", "a", "##a", "b", "##b", "ß", "ss",
+             "##s", "豈", "##1", "1"]
+    py, nat = _native_pair(extra)
+    alphabet = list("abcdeABCDE sS.,!?-'\"#_1 \t\n") + [
+        "Σ", "σ", "İ", "I", "é", "É", "ñ", "ü", "Å", "ǅ", "ß", "你", "好", "豈", "가", "한", "́", "̣", "̀", "­", "​",
+        " ", " ", "　", " ", " ", "\x00", "�", "\x1c", "\x85", "—", "…", "¿", "«", "༾",
+        "\U0001d165", "\U0001d16d", "\U0001f642", "\ud800", "ͅ", "ᾳ", "ΐ", "ﬁ", "Ǆ", "ẞ", "K", "Σ́", "Á̧"]
+    rng = random.Random(5)
+    cases = list(TEXTS) + ["ΑΣ ΑΣΑ Σ ΑΣ. ΑΣ'Α 'Σ Α.Σ", "İstanbul ISTANBUL", "가나다 한글", "x" * 101 + " ok", "a" * 100]
+    cases += ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 60))) for _ in range(1500)]
+    pools = [(0, 0x2FF), (0x300, 0x36F), (0x370, 0x2FFF), (0x3000, 0xFFFF), (0x10000, 0x2FFFF)]
+    cases += ["".join(chr(rng.randint(*rng.choice(pools))) for _ in range(rng.randint(1, 30))) for _ in range(800)]
+    got = nat.encode_batch(cases, 32)
+    for c, g in zip(cases, got):
+        assert g == py.encode(c, 32), repr(c)
+    for ml in (2, 3, 5):
+        for c in cases[:200]:
+            assert nat.encode(c, ml) == py.encode(c, ml), (c, ml)
+    ids, lens = nat.encode_batch_arrays(cases[:50], 32)
+    assert [ids[i, : lens[i]].tolist() for i in range(50)] == got[:50]
+
+
+def test_unicode_tables_are_current():
+    """csrc/unicode_tables.inc was generated from this interpreter's unicodedata"""
+    import unicodedata
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = open(os.path.join(root, "multimodal_rag_amd", "csrc", "unicode_tables.inc")).readline()
+    assert f"unicodedata {unicodedata.unidata_version}" in head, head
