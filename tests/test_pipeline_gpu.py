@@ -112,6 +112,45 @@ def test_embedding_manager_on_hip_engine(gpu, golden_dir):
     run(m.cleanup())
 
 
+def test_hip_engine_from_local_checkpoint_dir(gpu, tmp_path, monkeypatch):
+    """MMRAG_MODEL_DIR: config.json + model.safetensors + vocab.txt (+ sentence-transformers side files) -> native
+    tokenizer + DeviceEncoder; embeddings must equal the oracle fed by the Python tokenizer."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    from multimodal_rag_amd import embedder as EM
+    from multimodal_rag_amd.tokenizer import WordPieceTokenizer
+    from oracle import encoder_oracle as E
+    from tests.test_tokenizer import VOCAB
+
+    shape = E.BertShape(2, 128, 4, 256, len(VOCAB), 64, 1e-12, "mean")
+    w = E.make_bert_weights(shape, 3)
+    d = tmp_path / "tiny-bert"
+    (d / "1_Pooling").mkdir(parents=True)
+    save_file({"bert." + k: v for k, v in w.items()}, str(d / "model.safetensors"))
+    json.dump({"model_type": "bert", "num_hidden_layers": 2, "hidden_size": 128, "num_attention_heads": 4,
+               "intermediate_size": 256, "vocab_size": len(VOCAB), "max_position_embeddings": 64,
+               "layer_norm_eps": 1e-12}, open(d / "config.json", "w"))
+    json.dump({"pooling_mode_mean_tokens": True, "pooling_mode_cls_token": False}, open(d / "1_Pooling" / "config.json", "w"))
+    json.dump({"max_seq_length": 48}, open(d / "sentence_bert_config.json", "w"))
+    (d / "vocab.txt").write_text("\n".join(VOCAB) + "\n", encoding="utf-8")
+    monkeypatch.setattr(EM.settings, "MMRAG_MODEL_DIR", str(d))
+
+    eng = EM.HipEngine("whatever-name")
+    assert type(eng.tokenizer).__name__ == "NativeWordPieceTokenizer" and eng.max_seq_length == 48 and eng.dim == 128
+    texts = ["Machine learning là gì?", "The quick brown fox runs.", "unaffable running, naïve café! " * 20, "你好 state-of-the-art"]
+    got = eng.encode(texts)
+    py = WordPieceTokenizer({t: i for i, t in enumerate(VOCAB)})
+    want = E.bert_encode(shape, E.round_weights_fp16(w), [py.encode(t, 48) for t in texts])
+    assert np.abs(got - want).max() <= 4e-3 and (got * want).sum(1).min() >= 0.9999
+    # the list path and the array path of the encoder agree bit for bit
+    ids, lens = eng.tokenizer.encode_batch_arrays(texts, 48)
+    a = eng.encoder.encode_id_rows(ids, lens).cpu().numpy()
+    b = eng.encoder.encode_ids([ids[i, : lens[i]].tolist() for i in range(len(texts))]).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
 def test_clip_engine_joint_space(gpu, golden_dir, tmp_path):
     """BASELINE config 4: text chunks and images of arbitrary size in ONE index (CLIP ViT-B/32 shape, random
     weights); vectors must equal the towers driven directly, and search over the mixed index matches the oracle."""
