@@ -193,3 +193,39 @@ def test_bad_arguments_fail_loudly(N):
         N.cosine_topk(q, c, 11, 384, 5)
     with pytest.raises(N.MMRagNativeError):
         N.cosine_topk(q.cpu(), c.cpu(), 10, 384, 5)
+
+
+def test_randomised_shapes_against_oracle(N):
+    """60 random (B, n, d, k, dtype, mask, offset) draws, biased towards the kernel's seams: batch sizes around the
+    64/128/256-query shapes and their multiples, row counts around tile (256) and pre-pass (3 tiles per CU)
+    boundaries, dims around the 128-byte slab, all three list depths, sparse and dense alive masks."""
+    g = np.random.default_rng(2024)
+    seams_b = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513, 640]
+    seams_n = [1, 4, 5, 6, 255, 256, 257, 511, 513, 1000, 4099, 65_537, 196_607, 196_609, 230_000]
+    for trial in range(60):
+        B = int(g.choice(seams_b))
+        n = int(g.choice(seams_n))
+        d = int(g.choice([8, 33, 64, 96, 100, 128, 384]))
+        if n > 100_000:
+            d = min(d, 64)                      # keep the oracle's sgemm quick
+            B = min(B, 257)
+        k = int(g.choice([1, 3, 5, 6, 10, 17, 20]))
+        dtype = [torch.float16, torch.float32, torch.bfloat16][int(g.integers(3))]
+        alive = None
+        mode = int(g.integers(4))
+        if mode == 1:
+            alive = g.random(n) > 0.5
+        elif mode == 2:
+            alive = np.zeros(n, bool)
+            alive[g.integers(0, n, size=min(n, 7))] = True     # fewer live rows than k is possible
+        off = int(g.choice([0, 12345, 1 << 33]))
+        q = unit_rows(B, d, 1000 + trial)
+        c = unit_rows(n, d, 2000 + trial)
+        s, r, es, er = run(N, q, c, k, dtype, row_offset=off, alive=alive)
+        try:
+            check(s, r, es, er)
+            if alive is not None:
+                live = r[r >= 0] - off
+                assert np.all(alive[live])
+        except AssertionError as e:
+            raise AssertionError(f"trial {trial}: B={B} n={n} d={d} k={k} {dtype} mask={mode} off={off}") from e
