@@ -35,7 +35,7 @@ def _headers_mtime() -> float:
     m = 0.0
     for d in (CSRC, INCLUDE):
         for f in os.listdir(d):
-            if f.endswith(".h"):
+            if f.endswith((".h", ".inc")):
                 m = max(m, os.path.getmtime(os.path.join(d, f)))
     return m
 
