@@ -180,8 +180,12 @@ class NativeWordPieceTokenizer:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            self._lib.mmrag_wordpiece_destroy(h)
+        lib = getattr(self, "_lib", None)
+        if h and lib is not None:
+            try:
+                lib.mmrag_wordpiece_destroy(h)
+            except Exception:  # interpreter shutdown: the library may already be gone
+                pass
 
 
 class HashTokenizer:
