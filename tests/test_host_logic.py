@@ -284,3 +284,35 @@ def test_text_only_engines_keep_reference_behaviour_for_images():
     items = summaries(3, kinds=("image",))
     run(m.embed_and_store(items, "doc_bbbbbbbbbbbb"))
     assert not hasattr(eng, "encode_images") and eng.calls == [3]   # embedder.py:452: summaries are what is embedded
+
+
+# ---------------------------------------------------------------- metadata inverted index (index.MetaIndex)
+def test_meta_index_equals_full_scan():
+    from multimodal_rag_amd.index import MetaIndex, match_where
+
+    g = np.random.default_rng(3)
+    metas = []
+    for i in range(500):
+        m = {"doc_id": f"doc_{int(g.integers(7))}", "type": ["text", "table", "image"][int(g.integers(3))], "page": int(g.integers(5))}
+        if i % 50 == 0:
+            m["tags"] = ["a", "b"]          # unhashable value under another key
+        if i % 11 == 0:
+            del m["page"]
+        metas.append(m)
+    idx = MetaIndex()
+    idx.append(metas[:200])
+    idx.append(metas[200:])
+    wheres = [
+        None, {}, {"doc_id": "doc_3"}, {"doc_id": "nope"}, {"missing_key": "x"}, {"type": {"$eq": "image"}},
+        {"type": {"$in": ["text", "image"]}}, {"type": {"$in": []}}, {"doc_id": "doc_1", "type": "table"},
+        {"$and": [{"doc_id": "doc_2"}, {"page": 3}]}, {"$or": [{"doc_id": "doc_2"}, {"type": "image"}, {"page": 4}]},
+        {"$and": [{"$or": [{"page": 1}, {"page": 2}]}, {"type": "text"}]}, {"page": 0},
+    ]
+    for w in wheres:
+        want = [i for i, m in enumerate(metas) if match_where(m, w)]
+        got = idx.rows(w)
+        assert got is not None and got.tolist() == want, w
+    # forms outside the index fall back (None), never a wrong answer
+    for w in [{"page": {"$gt": 2}}, {"page": {"$ne": 1}}, {"tags": ["a", "b"]}, {"page": None}, {"type": {"$nin": ["text"]}}]:
+        got = idx.rows(w)
+        assert got is None or got.tolist() == [i for i, m in enumerate(metas) if match_where(m, w)], w
