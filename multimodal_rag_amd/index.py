@@ -257,11 +257,10 @@ class VectorIndex:
     def _alive_words(self, where: Optional[Dict[str, Any]]) -> Optional[np.ndarray]:
         if not where:
             return None
-        words = np.zeros((self._n + 31) // 32 + 8, dtype=np.uint32)
-        idx = self._rows_where(where)
-        if idx.size:
-            np.bitwise_or.at(words, idx // 32, np.uint32(1) << (idx % 32).astype(np.uint32))
-        return words
+        n_words = (self._n + 31) // 32 + 8
+        flags = np.zeros(n_words * 32, dtype=bool)
+        flags[self._rows_where(where)] = True
+        return np.packbits(flags, bitorder="little").view(np.uint32)   # bit r%32 of word r//32 = row r alive
 
     def _to_bits(self, words: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(words.view(np.int32)).to(self.device)
