@@ -38,10 +38,13 @@ logger = logging.getLogger(__name__)
 
 
 class ShardedCollection:
-    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None):
+    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None,
+                 shard_io=None):
         """`shard`: this rank's VectorIndex (or stand-in).  `device`: where collective buffers live
-        (the shard's GPU with the nccl backend, CPU with gloo)."""
+        (the shard's GPU with the nccl backend, CPU with gloo).  `shard_io`: (save(shard, directory),
+        load(directory) -> shard) used by save() / load(); default = persistence.save_index / load_index."""
         self.shard = shard
+        self._shard_io = shard_io
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -267,6 +270,59 @@ class ShardedCollection:
         self.shard.reset()
         self._seq_of.clear()
         self._id_of.clear()
+
+
+    # ------------------------------------------------------------------ save / load ---------
+    def save(self, directory: str):
+        """Persist every rank's shard (rows + tables + sequence numbers) under `directory`/rank_<r>."""
+        self._require_rank0()
+        self._run({"op": "save", "dir": directory})
+
+    def load(self, directory: str):
+        """Replace every rank's shard by what save() wrote (same world size)."""
+        self._require_rank0()
+        self._run({"op": "load", "dir": directory})
+
+    def _io(self):
+        if self._shard_io is not None:
+            return self._shard_io
+        from . import persistence
+
+        dev = str(getattr(self.shard, "device", "cuda:0"))
+        return persistence.save_index, (lambda d: persistence.load_index(d, device=dev))
+
+    def _do_save(self, cmd):
+        import json
+        import os
+
+        d = os.path.join(cmd["dir"], f"rank_{self.rank}")
+        os.makedirs(d, exist_ok=True)
+        self._io()[0](self.shard, d)
+        with open(os.path.join(d, "sequence.json"), "w", encoding="utf-8") as f:
+            json.dump({"world": self.world, "seq_of": self._seq_of}, f)
+        self._gather(True)                       # everyone has written before rank 0 returns
+        if self.rank == 0:
+            with open(os.path.join(cmd["dir"], "sharded.json"), "w", encoding="utf-8") as f:
+                json.dump({"world": self.world, "next_seq": self._next_seq}, f)
+
+    def _do_load(self, cmd):
+        import json
+        import os
+
+        d = os.path.join(cmd["dir"], f"rank_{self.rank}")
+        with open(os.path.join(d, "sequence.json"), encoding="utf-8") as f:
+            t = json.load(f)
+        if t["world"] != self.world:
+            raise ValueError(f"saved with {t['world']} ranks, loading with {self.world}")
+        self.shard = self._io()[1](d)
+        self._seq_of = {i: int(sq) for i, sq in t["seq_of"].items()}
+        self._id_of = {sq: i for i, sq in self._seq_of.items()}
+        parts = self._gather(list(self._seq_of))
+        if self.rank == 0:
+            with open(os.path.join(cmd["dir"], "sharded.json"), encoding="utf-8") as f:
+                self._next_seq = int(json.load(f)["next_seq"])
+            self._owner = {i: g for g, p in enumerate(parts) for i in p}
+            self._counts = [len(p) for p in parts]
 
 
 def _merge_deep(host: torch.Tensor, G: int, B: int, k: int):

@@ -51,6 +51,21 @@ def script(col):
     return out
 
 
+def fake_io():
+    """save / load of the numpy stand-in shard (the GPU build uses persistence.save_index / load_index)"""
+    def save(shard, d):
+        np.save(os.path.join(d, "vecs.npy"), shard.vecs, allow_pickle=False)
+        json.dump({"ids": shard.ids, "docs": shard.docs, "metas": shard.metas}, open(os.path.join(d, "t.json"), "w"))
+
+    def load(d):
+        c = FakeCollection(D)
+        t = json.load(open(os.path.join(d, "t.json")))
+        c.vecs, c.ids, c.docs, c.metas = np.load(os.path.join(d, "vecs.npy")), t["ids"], t["docs"], t["metas"]
+        return c
+
+    return save, load
+
+
 def manager_script(m):
     async def go():
         await m.initialize()
@@ -79,10 +94,20 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        col = ShardedCollection(FakeCollection(D))
+        col = ShardedCollection(FakeCollection(D), shard_io=fake_io())
         if rank == 0:
             out = script(col)
             out["shard_counts"] = list(col._counts)
+            # save, wipe, load: answers and later inserts behave as if nothing happened
+            v, ids, metas, docs, q = data()
+            before = col.query(q.tolist(), n_results=5)
+            col.save(os.path.join(out_dir, f"saved_{world}"))
+            col.reset()
+            assert col.count() == 0
+            col.load(os.path.join(out_dir, f"saved_{world}"))
+            out["reload_same"] = col.query(q.tolist(), n_results=5) == before and col.count() == out["count_after"]
+            col.add(v[120:122].tolist(), documents=["again", "again"], metadatas=metas[120:122], ids=["new_a", ids[130]])
+            out["reload_add"] = [col.count(), col.query(v[120:121].tolist(), n_results=2)["ids"][0]]
             col.stop()
         else:
             col.worker_loop()
@@ -128,7 +153,10 @@ def test_sharded_collection_equals_single_collection(tmp_path, world):
     want = json.loads(json.dumps(script(single)))           # same JSON round trip
     assert sum(got["shard_counts"]) == want["count_after"] and max(got["shard_counts"]) - min(got["shard_counts"]) <= 50
     for key in want:
-        assert _close(got[key], want[key]), key            # ids in the same ORDER: ties break by insertion order
+        assert _close(got[key], want[key]), key
+    assert got["reload_same"] is True
+    # after the reload: one new id accepted (an existing one ignored), and the new row ties with its twin by insertion order
+    assert got["reload_add"][0] == want["count_after"] + 1 and got["reload_add"][1] == ["doc_000000000002_text_120", "new_a"]            # ids in the same ORDER: ties break by insertion order
     assert got["q5"]["ids"][0][:2] == ["doc_000000000000_text_3", "doc_000000000002_text_100"]
 
     from multimodal_rag_amd.embedder import EmbeddingManager

@@ -25,7 +25,7 @@ def pg():
     dist.destroy_process_group()
 
 
-def test_sharded_collection_over_vector_index_matches_plain_index(pg):
+def test_sharded_collection_over_vector_index_matches_plain_index(pg, tmp_path):
     from multimodal_rag_amd.index import VectorIndex
     from multimodal_rag_amd.serving import ShardedCollection
 
@@ -61,6 +61,15 @@ def test_sharded_collection_over_vector_index_matches_plain_index(pg):
     got = col.get(ids=[ids[2500], ids[1001]], include=("documents", "embeddings"))
     want = plain.get(ids=[ids[2500], ids[1001]], include=("documents", "embeddings"))
     assert got["ids"] == want["ids"] and got["documents"] == want["documents"] and got["embeddings"] == want["embeddings"]
+    # save / wipe / load through persistence.save_index / load_index
+    before = col.query(q.tolist(), n_results=5)
+    col.save(str(tmp_path / "saved"))
+    col.reset()
+    assert col.count() == 0
+    col.load(str(tmp_path / "saved"))
+    assert col.count() == 2000 and col.query(q.tolist(), n_results=5) == before
+    col.add(v[:1].tolist(), documents=["back"], metadatas=metas[:1], ids=[ids[0]])
+    assert col.count() == 2001 and col.query(v[:1].tolist(), n_results=1)["ids"][0] == [ids[0]]
     col.reset()
     assert col.count() == 0
     col.stop()
