@@ -374,6 +374,21 @@ class EmbeddingManager:
 
         start_time = time.time()
         texts = [item["summary"] for item in summaries]
+        if getattr(self.collection, "encode_fn", None) is not None and not hasattr(self._engine, "encode_images"):
+            # multi-GPU serving loop with an encoder on every rank: ship the strings, each rank embeds and stores
+            # the items it owns (serving.ShardedCollection.add_texts)
+            counts = {"text": 0, "table": 0, "image": 0}
+            for item in summaries:
+                if item["type"] in counts:
+                    counts[item["type"]] += 1
+            await asyncio.to_thread(
+                self.collection.add_texts, texts, documents=texts,
+                metadatas=[{"doc_id": doc_id, "item_id": it["id"], "type": it["type"]} for it in summaries],
+                ids=[f"{doc_id}_{it['id']}" for it in summaries])
+            self.stats["total_items_stored"] += len(summaries)
+            logger.info("Stored %d embeddings for doc %s (data-parallel ingest) in %.2fs", len(summaries), doc_id,
+                        time.time() - start_time)
+            return counts
         embeddings = await self.embed_texts_batch(texts, show_progress=True)
         if hasattr(self._engine, "encode_images") and settings.MMRAG_EMBED_IMAGE_PIXELS:
             # joint-space engines (CLIP, BASELINE config 4): image items are embedded from their pixels

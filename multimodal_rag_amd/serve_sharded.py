@@ -35,7 +35,8 @@ class ShardedEngine:
 
     def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):
         if self._col is None:
-            self._col = ShardedCollection(self._engine.new_collection(name, metadata), self._group, self._device)
+            self._col = ShardedCollection(self._engine.new_collection(name, metadata), self._group, self._device,
+                                          encode_fn=self._engine.encode)
         else:                                # delete_all_documents re-creates the collection (embedder.py:670-678)
             self._col.reset()
         return self._col
@@ -79,12 +80,16 @@ def main(argv=None):
                 if sharded._col is not None:
                     sharded._col.stop()
         else:
-            from .index import VectorIndex
+            from .embedder import CLIP_MODEL_NAMES, ClipEngine, HipEngine, _is_clip_dir
 
             box = [None]
             dist.broadcast_object_list(box, src=0)
-            shard = VectorIndex(int(box[0]), dtype=index_dtype(), device=f"cuda:{local}", name=settings.CHROMA_COLLECTION_NAME)
-            ShardedCollection(shard, device=dev).worker_loop()
+            name = settings.SENTENCE_TRANSFORMER_MODEL
+            factory = ClipEngine if (name in CLIP_MODEL_NAMES or _is_clip_dir(settings.MMRAG_MODEL_DIR)) else HipEngine
+            engine = factory(name, f"cuda:{local}")      # every rank holds the encoder: ingest is data-parallel
+            assert engine.dim == int(box[0])
+            shard = engine.new_collection(settings.CHROMA_COLLECTION_NAME)
+            ShardedCollection(shard, device=dev, encode_fn=engine.encode).worker_loop()
     finally:
         dist.destroy_process_group()
 

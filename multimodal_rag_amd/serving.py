@@ -39,12 +39,16 @@ logger = logging.getLogger(__name__)
 
 class ShardedCollection:
     def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None,
-                 shard_io=None):
+                 shard_io=None, encode_fn=None):
         """`shard`: this rank's VectorIndex (or stand-in).  `device`: where collective buffers live
         (the shard's GPU with the nccl backend, CPU with gloo).  `shard_io`: (save(shard, directory),
         load(directory) -> shard) used by save() / load(); default = persistence.save_index / load_index."""
         self.shard = shard
         self._shard_io = shard_io
+        # data-parallel ingest: encode_fn(texts) -> [n, d] float32 on THIS rank (every rank holds the encoder);
+        # with it add_texts() ships strings, each rank embeds the items it will own and appends them locally --
+        # no vector leaves its GPU (SURVEY.md section 8e "Embed: no collective at all")
+        self.encode_fn = encode_fn
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -125,10 +129,38 @@ class ShardedCollection:
                 p["embeddings"] = np.asarray(p["embeddings"], dtype=np.float32)
             self._execute(self._command({"op": "add", "parts": parts}))
 
+    def add_texts(self, texts: Sequence[str], documents=None, metadatas=None, ids: Optional[Sequence[str]] = None):
+        """Ingest by text: every rank embeds and stores its own share (needs encode_fn on every rank)."""
+        self._require_rank0()
+        if self.encode_fn is None:
+            raise RuntimeError("add_texts needs an encode_fn on every rank")
+        n = len(texts)
+        if ids is None or len(ids) != n:
+            raise ValueError("ids are required, one per text")
+        documents = list(documents) if documents is not None else [None] * n
+        metadatas = list(metadatas) if metadatas is not None else [{} for _ in range(n)]
+        with self._lock:
+            parts: Dict[int, Dict[str, Any]] = {}
+            for i in range(n):
+                if ids[i] in self._owner:
+                    continue
+                r = int(np.argmin(self._counts))
+                self._owner[ids[i]] = r
+                self._counts[r] += 1
+                p = parts.setdefault(r, {"texts": [], "documents": [], "metadatas": [], "ids": [], "seqs": []})
+                p["seqs"].append(self._next_seq)
+                self._next_seq += 1
+                p["texts"].append(texts[i])
+                p["documents"].append(documents[i])
+                p["metadatas"].append(metadatas[i])
+                p["ids"].append(ids[i])
+            self._execute(self._command({"op": "add", "parts": parts}))
+
     def _do_add(self, cmd):
         p = cmd["parts"].get(self.rank)
         if p:
-            self.shard.add(p["embeddings"], documents=p["documents"], metadatas=p["metadatas"], ids=p["ids"])
+            emb = p["embeddings"] if "embeddings" in p else np.asarray(self.encode_fn(p["texts"]), dtype=np.float32)
+            self.shard.add(emb, documents=p["documents"], metadatas=p["metadatas"], ids=p["ids"])
             for i, sq in zip(p["ids"], p["seqs"]):
                 self._seq_of[i] = sq
                 self._id_of[sq] = i

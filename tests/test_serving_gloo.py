@@ -83,10 +83,15 @@ def manager_script(m):
 
 
 class ShardedEngine(FakeEngine):
-    """FakeEngine whose collections are sharded over the process group"""
+    """FakeEngine whose collections are sharded over the process group; with dp=True every rank embeds its own
+    share of an ingest (the encoder is replicated)"""
+
+    def __init__(self, dim, dp=False):
+        super().__init__(dim)
+        self.dp = dp
 
     def new_collection(self, name, metadata=None):
-        return ShardedCollection(FakeCollection(self.dim, name, metadata))
+        return ShardedCollection(FakeCollection(self.dim, name, metadata), encode_fn=self.encode if self.dp else None)
 
 
 def _worker(rank, world, port, out_dir):
@@ -114,14 +119,17 @@ def _worker(rank, world, port, out_dir):
         # second phase: the collection behind EmbeddingManager
         from multimodal_rag_amd.embedder import EmbeddingManager
 
-        eng = ShardedEngine(D)
-        m = EmbeddingManager(engine=eng)
+        for dp in (False, True):      # rank 0 embeds everything / every rank embeds its share
+            eng = ShardedEngine(D, dp=dp)
+            m = EmbeddingManager(engine=eng)
+            if rank == 0:
+                out["manager_dp" if dp else "manager"] = manager_script(m)
+                out["encode_calls_dp" if dp else "encode_calls"] = sum(eng.calls)
+                m.collection.stop()
+            else:
+                eng.new_collection("multimodal_rag").worker_loop()
         if rank == 0:
-            out["manager"] = manager_script(m)
-            m.collection.stop()
             json.dump(out, open(os.path.join(out_dir, f"sharded_{world}.json"), "w"))
-        else:
-            eng.new_collection("multimodal_rag").worker_loop()
     finally:
         dist.destroy_process_group()
 
@@ -162,4 +170,7 @@ def test_sharded_collection_equals_single_collection(tmp_path, world):
     from multimodal_rag_amd.embedder import EmbeddingManager
 
     m = EmbeddingManager(engine=FakeEngine(D))
-    assert _close(got["manager"], json.loads(json.dumps(manager_script(m))))
+    want_m = json.loads(json.dumps(manager_script(m)))
+    assert _close(got["manager"], want_m) and _close(got["manager_dp"], want_m)
+    # data-parallel ingest: rank 0 encoded only its share of the 60 chunks (plus the queries)
+    assert got["encode_calls_dp"] < got["encode_calls"] - 60 // world // 2

@@ -73,3 +73,36 @@ def test_sharded_collection_over_vector_index_matches_plain_index(pg, tmp_path):
     col.reset()
     assert col.count() == 0
     col.stop()
+
+
+def test_manager_over_sharded_engine_with_data_parallel_ingest(pg):
+    """serve_sharded.ShardedEngine (rank-0 side of the launcher) behind EmbeddingManager: ingest goes through
+    add_texts (each rank embeds its own share -- here the single rank), answers equal the plain engine's."""
+    import asyncio
+
+    from multimodal_rag_amd.embedder import EmbeddingManager, HipEngine
+    from multimodal_rag_amd.serve_sharded import ShardedEngine
+
+    items = [{"id": f"text_{i}", "summary": f"chunk {i} about subject {i % 9} " + "word " * (i % 13), "raw": "", "type": "text"}
+             for i in range(80)]
+
+    async def go(m):
+        await m.initialize()
+        counts = await m.embed_and_store(items, "doc_5eed5eed5eed")
+        r = await m.query("chunk 17 about subject 8", n_results=5)
+        b = await m.batch_query(["chunk 3 about subject 3", "chunk 44 about subject 8"], n_results=3)
+        n = (await m.get_collection_stats())["count"]
+        await m.delete_document("doc_5eed5eed5eed")
+        left = (await m.get_collection_stats())["count"]
+        return counts, r, b, n, left
+
+    plain = asyncio.run(go(EmbeddingManager(engine=HipEngine("all-MiniLM-L6-v2"))))
+    eng = ShardedEngine(HipEngine("all-MiniLM-L6-v2"), torch.device("cuda", 0))
+    m = EmbeddingManager(engine=eng)
+    sharded = asyncio.run(go(m))
+    assert eng._col is not None and eng._col.encode_fn is not None
+    assert sharded[0] == plain[0] == {"text": 80, "table": 0, "image": 0}
+    assert sharded[1]["ids"] == plain[1]["ids"] and np.allclose(sharded[1]["distances"], plain[1]["distances"], atol=1e-6)
+    assert [x["ids"] for x in sharded[2]] == [x["ids"] for x in plain[2]]
+    assert sharded[3:] == plain[3:] == (80, 0)
+    eng._col.stop()
