@@ -112,6 +112,58 @@ def test_embedding_manager_on_hip_engine(gpu, golden_dir):
     run(m.cleanup())
 
 
+def test_vector_index_under_concurrent_callers(gpu):
+    """the reference calls its engines from asyncio.to_thread workers (embedder.py:368, 517, 595) and batch_query
+    makes those calls concurrent: queries racing adds must each see a consistent index (every answer is the exact
+    top-k of SOME prefix of the inserts) and nothing may be lost"""
+    import threading
+
+    from multimodal_rag_amd.index import VectorIndex
+
+    d, n_batches, per = 128, 24, 250
+    V = unit(n_batches * per, d, 5)
+    q = unit(6, d, 6)
+    idx = VectorIndex(d, capacity=256)
+    idx.add(V[:per].tolist(), [f"d{i}" for i in range(per)], [{"type": "text"}] * per, [f"id{i}" for i in range(per)])
+    answers, errors = [], []
+
+    def writer():
+        try:
+            for b in range(1, n_batches):
+                lo = b * per
+                idx.add(V[lo:lo + per].tolist(), [f"d{i}" for i in range(lo, lo + per)], [{"type": "text"}] * per,
+                        [f"id{i}" for i in range(lo, lo + per)])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    def reader():
+        try:
+            for _ in range(40):
+                r = idx.query(q.tolist(), n_results=5)
+                answers.append((idx.count(), r["ids"], r["distances"]))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=writer)] + [threading.Thread(target=reader) for _ in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert idx.count() == n_batches * per
+    stored = V.astype(np.float16).astype(np.float32)
+    qs = q.astype(np.float16).astype(np.float32)
+    prefix_answers = {}
+    for m in range(per, n_batches * per + 1, per):
+        es, er = O.cosine_topk(qs, stored[:m], 5)
+        prefix_answers[m] = [[f"id{r}" for r in row] for row in er]
+    for count_after, ids, dist in answers:
+        assert any(ids == prefix_answers[m] for m in prefix_answers if m <= count_after), "answer matches no insert prefix"
+        assert all(a <= b + 1e-7 for row in dist for a, b in zip(row, row[1:]))
+    final = idx.query(q.tolist(), n_results=5)
+    assert final["ids"] == prefix_answers[n_batches * per]
+
+
 def test_hip_engine_from_local_checkpoint_dir(gpu, tmp_path, monkeypatch):
     """MMRAG_MODEL_DIR: config.json + model.safetensors + vocab.txt (+ sentence-transformers side files) -> native
     tokenizer + DeviceEncoder; embeddings must equal the oracle fed by the Python tokenizer."""
