@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--rows", type=int, default=N_TOTAL, help="total corpus rows (default: the 1M headline)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hnsw-baseline", type=int, default=0, metavar="ROWS",
+                    help="also time the HNSW restatement of chromadb's approximate index (oracle/hnsw_oracle.cpp, "
+                         "Chroma's defaults) on the first ROWS corpus rows: build time, queries/s, recall@5. Opt-in: "
+                         "the graph build takes minutes.")
     ap.add_argument("--no-embed", action="store_true")
     ap.add_argument("--merge", choices=["host", "device"], default="host",
                     help="where the G*k -> k merge runs for N > 1 (north star: host)")
@@ -278,6 +282,31 @@ def main():
                       f"{n_local} rows, best of 2; host cpu_count={os.cpu_count()}",
         }
         result["parity_vs_oracle"] = ok
+        if args.hnsw_baseline > 0:
+            from oracle.hnsw_oracle import HnswIndex
+
+            m = min(args.hnsw_baseline, n_local)
+            sub = np.ascontiguousarray(c_host[:m], dtype=np.float32)
+            t0 = time.perf_counter()
+            hidx = HnswIndex(sub)
+            t_build = time.perf_counter() - t0
+            xs, xr = O.cosine_topk(q_host, sub, k)
+            leg = {"kind": "restatement of chroma-hnswlib's algorithm, not chromadb (parity unpinned)",
+                   "rows": m, "M": 16, "ef_construction": 100, "build_s": round(t_build, 1),
+                   "build_threads": hidx.n_threads, "search": []}
+            for ef in (10, 100):
+                hidx.search(q_host, k, ef, n_threads=1)
+                t0 = time.perf_counter()
+                hs, hr = hidx.search(q_host, k, ef, n_threads=1)
+                t1 = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                hidx.search(q_host, k, ef)
+                tn = time.perf_counter() - t0
+                rec = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(hr.tolist(), xr.tolist())]))
+                leg["search"].append({"ef": ef, "recall_at_5": round(rec, 3), "queries_per_s_1_thread": round(B / t1, 1),
+                                      "queries_per_s_all_threads": round(B / tn, 1)})
+            result["cpu_baseline_hnsw"] = leg
+            del sub, hidx
         del c_host
 
     if not args.no_embed:
