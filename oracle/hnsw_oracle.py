@@ -1,6 +1,6 @@
 """TEST / MEASUREMENT INFRASTRUCTURE ONLY.  ctypes wrapper of oracle/hnsw_oracle.cpp (the HNSW restatement of the
 approximate index chromadb queries; see that file's header).  Compiled on first use with g++ on the machine it
-runs on (`-march=native`), into oracle/_build/ (git-ignored).  Used by bench.py's optional `--hnsw-baseline`
+runs on (`-O3 -mavx2 -mfma`), into oracle/_build/ (git-ignored).  Used by bench.py's optional `--hnsw-baseline`
 and by tests/test_oracle_hnsw.py; never by the product path."""
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ def lib():
         src = os.path.join(_HERE, "hnsw_oracle.cpp")
         if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
             os.makedirs(os.path.dirname(_SO), exist_ok=True)
-            subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-shared", "-fPIC", "-pthread", src, "-o", _SO],
+            subprocess.run(["g++", "-O3", "-mavx2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-pthread", src, "-o", _SO],
                            check=True)
         _lib = ctypes.CDLL(_SO)
         _lib.hnsw_build.restype = ctypes.c_void_p
