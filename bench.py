@@ -81,6 +81,20 @@ def cpu_baseline(q_host: np.ndarray, corpus_host: np.ndarray, k: int):
     s, r = O.cosine_topk(q_host, corpus_host, k)
     t2 = time.perf_counter()
     dt = min(t1 - t0, t2 - t1)
+    # a GPU box hands one job a share of its cores (16 per GPU): also try the BLAS pool at that size and report
+    # the better run with ITS thread count
+    try:
+        from threadpoolctl import threadpool_limits
+
+        if threads > 16:
+            with threadpool_limits(limits=16, user_api="blas"):
+                t3 = time.perf_counter()
+                O.cosine_topk(q_host, corpus_host, k)
+                d16 = time.perf_counter() - t3
+            if d16 < dt:
+                dt, threads = d16, 16
+    except Exception:
+        pass
     return s, r, dt, threads
 
 
@@ -279,7 +293,7 @@ def main():
         result["cpu_baseline"] = {
             "value": round(B / cdt, 1), "unit": "queries/s", "cores": threads, "kind": "port",
             "sample": f"oracle/search_oracle.py (numpy/OpenBLAS sgemm + exact top-k) on {B} queries x "
-                      f"{n_local} rows, best of 2; host cpu_count={os.cpu_count()}",
+                      f"{n_local} rows, best of 2 (and once at 16 BLAS threads); host cpu_count={os.cpu_count()}",
         }
         result["parity_vs_oracle"] = ok
         if args.hnsw_baseline > 0:

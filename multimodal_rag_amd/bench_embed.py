@@ -127,18 +127,27 @@ def cpu_baseline_torch(cfg, ids_np, batch: int = 32):
                                 max_position_embeddings=cfg.max_pos, layer_norm_eps=cfg.ln_eps)
     model = transformers.BertModel(c, add_pooling_layer=False).eval()
     x = torch.from_numpy(ids_np[:batch].astype(np.int64))
-    best = None
-    with torch.no_grad():
-        for _ in range(3):
-            t0 = time.perf_counter()
-            h = model(input_ids=x).last_hidden_state
-            e = h[:, 0] if cfg.pool == "cls" else h.mean(1)
-            e = torch.nn.functional.normalize(e, dim=1)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-    return {"value": round(batch / best, 2), "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+    best, best_threads = None, torch.get_num_threads()
+    default_threads = torch.get_num_threads()
+    # a GPU box hands one job a share of its cores (16 per GPU): the default thread count (all cores of the host)
+    # oversubscribes that share, so try the share too and report the better one with ITS thread count
+    try:
+        with torch.no_grad():
+            for threads in sorted({default_threads, min(default_threads, 16)}):
+                torch.set_num_threads(threads)
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    h = model(input_ids=x).last_hidden_state
+                    e = h[:, 0] if cfg.pool == "cls" else h.mean(1)
+                    e = torch.nn.functional.normalize(e, dim=1)
+                    dt = time.perf_counter() - t0
+                    if best is None or dt < best:
+                        best, best_threads = dt, threads
+    finally:
+        torch.set_num_threads(default_threads)
+    return {"value": round(batch / best, 2), "unit": "chunks/s", "cores": best_threads, "kind": "port",
             "sample": f"transformers.BertModel fp32 on CPU (the module sentence-transformers wraps), {batch} chunks x "
-                      f"{x.shape[1]} tokens (reference batch size, api.py:93), best of 3"}
+                      f"{x.shape[1]} tokens (reference batch size, api.py:93), best of 2 at 16 and at all threads"}
 
 
 def synthetic_vocab(n: int = 30522, seed: int = 11):
