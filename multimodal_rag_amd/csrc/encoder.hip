@@ -760,6 +760,87 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const _Float16 *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Few tokens (M <= 64): the online /query path embeds ONE short text (reference embedder.py:539-583),
+// where the tiled kernel above runs a handful of workgroups through a long serial K loop (20 us for
+// MiniLM's FFN2).  Here one workgroup owns 32 output features; its four waves split K four ways, read
+// the MFMA fragments straight from global memory (the operands are a few hundred KB, L2-resident),
+// and the partial 32x32 tiles are summed through LDS.  Same arithmetic order inside a k-step as the tiled
+// kernel, but a different split of K, so results differ from it in the last fp32 bit -- parity is against
+// the oracle, as for every kernel.
+// ---------------------------------------------------------------------------------------------
+template <int NWC>  // waves that split K (4, 8 or 16); the first four also reduce and store
+__global__ __launch_bounds__(64 * NWC) void linear_small_kernel(const LinearParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float part[NWC][16][64];  // [wave][register][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int f0 = blockIdx.x * 32;
+    const int kw = p.K / NWC;               // this wave's share of K (a multiple of 16, checked by the launcher)
+    const int k_lo = wave * kw;
+    const int fr = f0 + r32 < p.N ? f0 + r32 : p.N - 1;   // clamped: out-of-range rows are computed and dropped
+    const _Float16 *wrow = (const _Float16 *)p.wt + (size_t)fr * p.K + k_lo + 8 * h;
+    for (int t0 = 0; t0 < p.M; t0 += 32) {
+        const int tr = t0 + r32 < p.M ? t0 + r32 : p.M - 1;
+        const _Float16 *xrow = (const _Float16 *)p.x + (size_t)tr * p.K + k_lo + 8 * h;
+        f32x16_t acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+        for (int k = 0; k < kw; k += 64) {   // 4 k-steps per trip: 8 independent 16-byte loads in flight
+            half8_t a[4], b[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const bool in = k + 16 * s_ < kw;
+                a[s_] = *(const half8_t *)(wrow + (in ? k + 16 * s_ : 0));
+                b[s_] = *(const half8_t *)(xrow + (in ? k + 16 * s_ : 0));
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                if (k + 16 * s_ < kw) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_], b[s_], acc, 0, 0, 0);
+        }
+        if (t0 > 0) __syncthreads();  // the previous token block's partials have been consumed
+#pragma unroll
+        for (int j = 0; j < 16; ++j) part[wave][j][lane] = acc[j];
+        __syncthreads();
+        // wave g < 4 reduces register group g: features f0 + 8 g + 4 h + (0..3) of token t0 + r32
+        const int g = wave & 3;
+        const int t = t0 + r32;
+        const int f = f0 + 8 * g + 4 * h;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave < 4) {
+#pragma unroll
+            for (int w = 0; w < NWC; ++w)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += part[w][4 * g + i][lane];
+        }
+        if (wave < 4 && t < p.M && f < p.N) {   // N % 4 == 0: a group of four features is in range together
+            if (p.bias != nullptr) {
+                const float4 bv = *(const float4 *)(p.bias + f);
+                v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
+            }
+            half4_t o;
+            if (p.act == MMRAG_ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply<MMRAG_ACT_GELU>(v[i]);
+            } else if (p.act == MMRAG_ACT_QUICK_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply<MMRAG_ACT_QUICK_GELU>(v[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
+            }
+            if (p.resid != nullptr) {
+                const half4_t rv = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)((float)o[i] + (float)rv[i]);
+            }
+            *(half4_t *)(p.out + (size_t)t * p.N + f) = o;
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 int launch_linear(const void *x, int M, int K, const void *wt, int N, const float *bias, int act,
@@ -772,6 +853,14 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
     p.out = (_Float16 *)out;
     p.M = M, p.N = N, p.K = K, p.act = act;
     p.xcd_order = getenv("MMRAG_LINEAR_PLAIN") ? 0 : 1;
+    if (M <= 64 && (K / 4) % 16 == 0 && !getenv("MMRAG_LINEAR_NO_SMALL")) {
+        // the online single-query path: split-K over the 16 / 8 / 4 waves of a 32-feature workgroup
+        const unsigned g = (unsigned)((N + 31) / 32);
+        if (K % 256 == 0) linear_small_kernel<16><<<g, 1024, 0, s>>>(p);
+        else if (K % 128 == 0) linear_small_kernel<8><<<g, 512, 0, s>>>(p);
+        else linear_small_kernel<4><<<g, 256, 0, s>>>(p);
+        return MMRAG_OK;
+    }
     const int cus = num_cus();
     const long long big_tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
     // a ragged last feature tile (N % 256 != 0) wastes part of its MFMAs but still beats the small tile while

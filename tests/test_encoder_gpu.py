@@ -63,6 +63,24 @@ def test_linear(N, M, K, Nf, act, with_resid):
     assert np.abs(got - y).max() <= 2e-3 * scale, float(np.abs(got - y).max())
 
 
+@pytest.mark.parametrize("M,K,Nf", [(1, 384, 384), (7, 384, 1152), (16, 1536, 384), (32, 384, 1536), (33, 768, 2304),
+                                   (64, 3072, 768), (5, 512, 100), (40, 64, 36), (64, 2048, 512)])
+@pytest.mark.parametrize("act,with_resid", [(0, False), (1, False), (0, True), (2, True)])
+def test_linear_few_tokens(N, M, K, Nf, act, with_resid):
+    """M <= 64 takes the split-K kernel of the single-query path (ragged feature blocks, 1-2 token blocks)"""
+    test_linear(N, M, K, Nf, act, with_resid)
+
+
+def test_linear_few_tokens_exact_integers(N):
+    g = np.random.default_rng(2)
+    for M, K, Nf in ((3, 192, 68), (64, 448, 96), (33, 1536, 32)):
+        x = g.integers(-4, 5, (M, K)).astype(np.float32)
+        w = g.integers(-2, 3, (Nf, K)).astype(np.float32)
+        w[:, 0] += np.arange(Nf) % 5
+        out = N.linear_f16(dev16(x), dev16(w))
+        assert np.array_equal(out.float().cpu().numpy(), x @ w.T), (M, K, Nf)
+
+
 def test_linear_exact_integers(N):
     """integer data is exact in fp16 x fp16 -> fp32: catches any fragment / epilogue index swap"""
     g = np.random.default_rng(0)
