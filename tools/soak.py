@@ -47,9 +47,14 @@ async def main(seconds):
     es, er = O.cosine_topk(qs.astype(np.float16).astype(np.float32), V.astype(np.float16).astype(np.float32), 5)
     want = [[got["ids"][r] for r in row] for row in er]
     same = sum(a == b for a, b in zip(res["ids"], want))
-    stats["checked"] = len(want); stats["final_rows"] = len(V); stats["final_exact_matches"] = same
+    row_of = {i: n for n, i in enumerate(got["ids"])}
+    got_rows = np.array([[row_of[i] for i in row] for row in res["ids"]])
+    stats["checked"] = len(want); stats["final_rows"] = len(V); stats["identical_lists"] = same
     print(stats)
-    assert same >= len(want) - 2          # ties within fp16 rounding may permute equal scores
+    # BASELINE section 4 rule: same id sets, candidates within 2e-4 of the k-th score interchangeable (these
+    # generated texts are near-duplicates, so ties at the 1e-7 level are common)
+    assert O.same_topk_sets(got_rows, 1 - np.array(res["distances"]), er, es)
+    assert np.allclose(1 - np.array(res["distances"]), es, atol=1e-4)
     await m.cleanup()
 
 asyncio.run(main(float(sys.argv[1]) if len(sys.argv) > 1 else 20.0))
