@@ -43,6 +43,10 @@ def _declare(lib):
     lib.mmrag_cosine_topk_lists.restype = c_int
     lib.mmrag_cosine_topk_lists.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_int,
                                             c_void_p, c_void_p, c_size_t, c_void_p]
+    # debug form of mmrag_cosine_topk_lists (kernel-shape switches; csrc/search.hip, not in include/mmrag.h)
+    lib.mmrag_internal_cosine_topk_lists_ex.restype = c_int
+    lib.mmrag_internal_cosine_topk_lists_ex.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int,
+                                                        c_int, c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_uint]
     lib.mmrag_cosine_topk_select.restype = c_int
     lib.mmrag_cosine_topk_select.argtypes = [c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.mmrag_merge_topk.restype = c_int
@@ -134,9 +138,13 @@ def padded_dim(d: int, dtype: torch.dtype) -> int:
     return int(v)
 
 
+# kernel-shape switches of the debug entry point (tests / A-B tools; the product always passes 0)
+DBG_NO_PREPASS, DBG_8_WAVES, DBG_NO_QS, DBG_QS_4_WAVES = 1, 2, 4, 8
+
+
 def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, row_offset: int = 0,
                 alive_bits: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                workspace: Optional[torch.Tensor] = None, dbg: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact cosine top-k of q [B, ld] against the first n rows of corpus [cap, ld].
 
     Returns (scores [B, k] float32 descending, rows [B, k] int64 global).  Both inputs must be
@@ -156,6 +164,9 @@ def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, r
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
     out_s = torch.empty((B, k), dtype=torch.float32, device=q.device)
     out_r = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    if dbg:
+        cosine_topk_lists(q, corpus, n, d, k, workspace, alive_bits=alive_bits, dbg=dbg)
+        return cosine_topk_select(B, n, k, row_offset, workspace, out_s, out_r)
     with torch.cuda.device(q.device):
         st = L.mmrag_cosine_topk(q.data_ptr(), corpus.data_ptr(), B, n, d, ld, _TORCH2DT[q.dtype], k, row_offset,
                                  alive_bits.data_ptr() if alive_bits is not None else None,
@@ -246,7 +257,7 @@ def fetch_rows_f32(corpus: torch.Tensor, rows: torch.Tensor, d: int) -> torch.Te
 
 
 def cosine_topk_lists(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, workspace: torch.Tensor,
-                      alive_bits: Optional[torch.Tensor] = None) -> None:
+                      alive_bits: Optional[torch.Tensor] = None, dbg: int = 0) -> None:
     """Phase 1 of cosine_topk: the fused GEMM + selection kernel; candidates stay in `workspace`."""
     _dev_check(q, corpus, workspace, alive_bits)
     if q.dtype != corpus.dtype or q.shape[1] != corpus.shape[1] or not q.is_contiguous() or not corpus.is_contiguous():
@@ -255,10 +266,10 @@ def cosine_topk_lists(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: 
         raise MMRagNativeError(f"cosine_topk_lists: n={n} exceeds corpus capacity {corpus.shape[0]}")
     B, ld = q.shape
     with torch.cuda.device(q.device):
-        st = lib().mmrag_cosine_topk_lists(q.data_ptr(), corpus.data_ptr(), B, n, d, ld, _TORCH2DT[q.dtype], k,
-                                           alive_bits.data_ptr() if alive_bits is not None else None,
-                                           workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-                                           _stream_ptr(q.device))
+        st = lib().mmrag_internal_cosine_topk_lists_ex(
+            q.data_ptr(), corpus.data_ptr(), B, n, d, ld, _TORCH2DT[q.dtype], k,
+            alive_bits.data_ptr() if alive_bits is not None else None, workspace.data_ptr(),
+            workspace.numel() * workspace.element_size(), _stream_ptr(q.device), int(dbg))
     _check(st, "mmrag_cosine_topk_lists")
 
 

@@ -24,10 +24,8 @@
 //     the epilogue;
 //   * every lane list is written once at kernel end; a second tiny kernel merges the
 //     gridDim.x * WM * 2 lists per query into the final [B, k] (ties -> lower row).
-#include "mmrag_internal.h"
-#include "tile_dma.h"
+#include "search_shared.h"
 
-#include <limits.h>
 #include <stdlib.h>
 
 using namespace mmrag;
@@ -36,73 +34,6 @@ namespace mmrag_impl {
 
 constexpr int TM = 256;            // corpus rows per tile
 constexpr int CORPUS_STAGE = TM * SLAB;  // 32 KiB
-constexpr float NEG_INF = -__builtin_inff();
-
-__device__ inline bool better(float s, long long r, float s2, long long r2) {
-    return s > s2 || (s == s2 && r < r2);
-}
-
-template <int K>
-struct TopList {
-    float v[K];
-    int r[K];
-    __device__ inline void init() {
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            v[i] = NEG_INF;
-            r[i] = INT_MAX;
-        }
-    }
-    // full (score desc, row asc) order: for merging lists whose rows interleave
-    __device__ inline void insert_ordered(float x, int xr) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const bool b = x > v[j] || (x == v[j] && xr < r[j]);
-            const float nv = b ? x : v[j];
-            const float nx = b ? v[j] : x;
-            const int nr = b ? xr : r[j];
-            const int nxr = b ? r[j] : xr;
-            v[j] = nv;
-            x = nx;
-            r[j] = nr;
-            xr = nxr;
-        }
-    }
-    // insertion order == row order inside a lane, so "strictly greater" keeps the lower row on ties
-    __device__ inline void insert_strict(float x, int xr) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const bool b = x > v[j];
-            const float nv = b ? x : v[j];
-            const float nx = b ? v[j] : x;
-            const int nr = b ? xr : r[j];
-            const int nxr = b ? r[j] : xr;
-            v[j] = nv;
-            x = nx;
-            r[j] = nr;
-            xr = nxr;
-        }
-    }
-};
-
-
-struct KParams {
-    const char *q;        // [B, ld]
-    const char *corpus;   // [n, ld]
-    const uint32_t *alive_bits;
-    float *cand_s;        // [Bpad, n_lists, K]
-    int *cand_r;
-    long long n;
-    int B;
-    unsigned row_bytes;   // ld * esize, multiple of 128
-    int n_tiles;
-    int n_lists;          // list slots per query in cand_* (>= gridDim.x)
-    int tile0;            // first corpus tile of this launch (sample pre-pass / main pass split)
-    int walkers;          // workgroups that walk the tiles, per query group (grid = walkers * query groups)
-    int share_l2;         // > 1 query group: corpus slabs are re-read by the sibling groups, keep them in L2
-    const float *thr0;    // optional [B]: a known lower bound of each query's final k-th score
-};
-
 
 template <int DT, int WN, int K, int NSTAGE, int NW, bool SEEDED>
 __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KParams p) {
@@ -547,9 +478,15 @@ struct Plan {
     int n_lists;
     int b_pad;
     int pre_tiles;  // > 0: a sample pre-pass over the first pre_tiles tiles seeds the selection thresholds
+    bool qs_ok;     // shape admits the query-stationary kernel (search_qs.hip) when dtype / row length do
 };
 
-Plan make_plan(int B, long long n, int k) {
+// debug switches of mmrag_internal_cosine_topk_lists_ex (tests and A/B tools only; never set by the product)
+constexpr unsigned DBG_NO_PREPASS = 1u, DBG_8_WAVES = 2u, DBG_NO_QS = 4u;
+
+// n_lists, b_pad and pre_tiles depend on (B, n, k) only: mmrag_cosine_topk_select and the workspace query
+// have no dtype, so both kernels keep the same list layout
+Plan make_plan(int B, long long n, int k, unsigned dbg = 0) {
     Plan pl;
     pl.K = k <= 5 ? 5 : (k <= 10 ? 10 : 20);
     pl.WN = B <= 64 ? 2 : (B <= 128 ? 4 : 8);
@@ -564,15 +501,19 @@ Plan make_plan(int B, long long n, int k) {
         pl.grid_x = w >= 8 ? w : (cus / pl.grid_y > 0 ? cus / pl.grid_y : 1);
     }
     if (pl.grid_x < 1) pl.grid_x = 1;
-    pl.NW = (pl.K == 5 && pl.WN == 8 && !getenv("MMRAG_NW8")) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
+    pl.NW = (pl.K == 5 && pl.WN == 8 && !(dbg & DBG_8_WAVES)) ? 16 : 8;  // 4 waves/SIMD hide LDS + barrier latency
     // Sample pre-pass (256-query shape, and every shape with deep lists: there the epilogue, not HBM, is
     // what thresholds relieve).
     // The exact top-K of the first `cus` tiles gives every query a threshold as tight as if each
     // workgroup had already seen 65k rows, so the main pass almost never takes the insertion path.
     pl.pre_tiles = 0;
-    if ((pl.WN == 8 || pl.K > 5) && pl.n_tiles >= 3 * cus && !getenv("MMRAG_NO_PREPASS")) pl.pre_tiles = cus;
-    pl.n_lists = pl.grid_x + (pl.pre_tiles ? 1 : 0);  // one merged list per workgroup per query (+ the sample's)
+    const bool want_pre = (pl.WN == 8 || pl.K > 5) && pl.n_tiles >= 3 * cus;
+    if (want_pre && !(dbg & DBG_NO_PREPASS)) pl.pre_tiles = cus;
+    pl.n_lists = pl.grid_x + (want_pre ? 1 : 0);  // one merged list per workgroup per query (+ the sample's)
     pl.b_pad = pl.grid_y * qrows;
+    // query-stationary kernel: more than 128 queries, and a shard big enough that every walker of the
+    // slab-ring plan (same grid, same list slots) gets 64-row tiles of its own
+    pl.qs_ok = pl.WN == 8 && pl.n_tiles >= cus && !(dbg & DBG_NO_QS);
     return pl;
 }
 
@@ -636,6 +577,15 @@ __global__ void fill_empty_kernel(float *s, long long *r, long long total) {
     }
 }
 
+__global__ void fill_seed_empty_kernel(float *s, int *r, long long q_stride, int K, long long n_queries) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_queries)
+        for (int i = 0; i < K; ++i) {
+            s[q * q_stride + i] = NEG_INF;
+            r[q * q_stride + i] = INT_MAX;
+        }
+}
+
 }  // namespace mmrag_impl
 using namespace mmrag_impl;
 
@@ -679,12 +629,14 @@ static int check_search_args(const void *q, const void *corpus, int B, int64_t n
     return MMRAG_OK;
 }
 
-int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
-                            int k, const uint32_t *alive_bits, void *workspace, size_t workspace_bytes,
-                            void *stream) {
+// mmrag_cosine_topk_lists with debug switches (DBG_*): kernel-shape A/B runs and the tests that pin every code
+// path against the oracle.  Exported for them, deliberately absent from include/mmrag.h.
+int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld,
+                                        int dtype, int k, const uint32_t *alive_bits, void *workspace,
+                                        size_t workspace_bytes, void *stream, unsigned dbg) {
     if (int st = check_search_args(q, corpus, B, n, d, ld, dtype, k)) return st;
     if (n == 0) return MMRAG_OK;
-    const Plan pl = make_plan(B, n, k);
+    const Plan pl = make_plan(B, n, k, dbg);
     const WsLayout wl = ws_layout(pl);
     if (!workspace || workspace_bytes < wl.total) {
         set_error("cosine_topk: workspace %zu bytes < required %zu", workspace_bytes, wl.total);
@@ -705,43 +657,64 @@ int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n,
     p.n_lists = pl.n_lists;
     p.tile0 = 0;
     p.thr0 = nullptr;
+    p.dbg = dbg;
+    p.stamps = ((dbg & DBG_QS_CLOCK) && workspace_bytes >= wl.total + 16 * (size_t)(pl.grid_x * pl.grid_y)) ? (unsigned long long *)((char *)workspace + wl.total) : nullptr;
+    p.walkers = pl.grid_x;
+    p.share_l2 = pl.grid_y > 1;
     hipStream_t s = (hipStream_t)stream;
-    auto run = [&](const Plan &lp, const KParams &kp) {
-        if (dtype == MMRAG_F32) dispatch_main<MMRAG_F32>(lp, kp, s);
-        else if (dtype == MMRAG_F16) dispatch_main<MMRAG_F16>(lp, kp, s);
-        else dispatch_main<MMRAG_BF16>(lp, kp, s);
+    // tile units: 256 rows for the slab-ring kernel, QS_TILE_ROWS for the query-stationary one
+    const bool qs = pl.qs_ok && qs_supported(dtype, p.row_bytes, pl.K);
+    const int qs_rows = qs_tile_rows(dbg);
+    const int unit = qs ? TM / qs_rows : 1;
+    const int tiles_total = qs ? (int)((n + qs_rows - 1) / qs_rows) : pl.n_tiles;
+    auto run = [&](int tile0, int n_tiles, int grid_x, const float *thr0) -> int {
+        KParams kp = p;
+        kp.tile0 = tile0;
+        kp.n_tiles = n_tiles;
+        kp.thr0 = thr0;
+        if (qs) return qs_launch(dtype, pl.K, kp, grid_x, pl.grid_y, s);
+        Plan lp = pl;
+        lp.grid_x = grid_x;
+        if (dtype == MMRAG_F32) return dispatch_main<MMRAG_F32>(lp, kp, s);
+        if (dtype == MMRAG_F16) return dispatch_main<MMRAG_F16>(lp, kp, s);
+        return dispatch_main<MMRAG_BF16>(lp, kp, s);
     };
+    const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the sample's list: last slot of every query
     if (pl.pre_tiles > 0) {
-        // 1. sample pre-pass over tiles [0, pre_tiles): one tile per workgroup
+        // 1. sample pre-pass over the first pre_tiles * 256 rows, spread over the walkers
         float *thr0 = (float *)((char *)workspace + wl.off_thr);
         float *top_s = (float *)((char *)workspace + wl.off_ts);
         long long *top_r = (long long *)((char *)workspace + wl.off_tr);
-        Plan pre = pl;
-        pre.n_tiles = pl.pre_tiles;
-        pre.grid_x = pl.pre_tiles < pl.grid_x ? pl.pre_tiles : pl.grid_x;
-        KParams kp = p;
-        kp.n_tiles = pre.n_tiles;
-        run(pre, kp);
+        int pre = pl.pre_tiles * unit;
+        if (qs && ((dbg >> 14) & 3u)) pre = pl.grid_x * (int)((dbg >> 14) & 3u);  // A/B: sample tiles per walker
+        const int pre_grid = pre < pl.grid_x ? pre : pl.grid_x;
+        if (int st = run(0, pre, pre_grid, nullptr)) return st;
         MMRAG_CHECK_HIP(hipGetLastError());
         // 2. its exact top-K per query, 3. seed thresholds + keep it as the last candidate list
-        const long long n_cand = (long long)pre.grid_x * pl.K;
-        const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the last list slot of every query
+        const long long n_cand = (long long)pre_grid * pl.K;
         launch_merge<int>(pl.K, p.cand_s, p.cand_r, n_cand, n_cand, 0, (long long)pl.n_lists * pl.K, B, pl.K, 0, top_s,
                           top_r, s, thr0, p.cand_s + seed_off, p.cand_r + seed_off, (long long)pl.n_lists * pl.K);
         MMRAG_CHECK_HIP(hipGetLastError());
         // 4. main pass over the remaining tiles, selection armed with the sample thresholds
-        Plan mainp = pl;
-        mainp.n_tiles = pl.n_tiles - pl.pre_tiles;
-        KParams km = p;
-        km.n_tiles = mainp.n_tiles;
-        km.tile0 = pl.pre_tiles;
-        km.thr0 = thr0;
-        run(mainp, km);
+        if (int st = run(pre, tiles_total - pre, pl.grid_x, thr0)) return st;
     } else {
-        run(pl, p);
+        if (pl.n_lists > pl.grid_x) {
+            // (debug: pre-pass switched off) the sample's list slot exists but nothing fills it
+            const long long total = (long long)pl.b_pad;
+            fill_seed_empty_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
+                p.cand_s + seed_off, p.cand_r + seed_off, (long long)pl.n_lists * pl.K, pl.K, total);
+        }
+        if (int st = run(0, tiles_total, pl.grid_x, nullptr)) return st;
     }
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;
+}
+
+int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
+                            int k, const uint32_t *alive_bits, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    return mmrag_internal_cosine_topk_lists_ex(q, corpus, B, n, d, ld, dtype, k, alive_bits, workspace,
+                                               workspace_bytes, stream, 0u);
 }
 
 int mmrag_cosine_topk_select(int B, int64_t n, int k, int64_t row_offset, const void *workspace,

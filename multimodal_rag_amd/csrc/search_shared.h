@@ -1,0 +1,93 @@
+// Types shared by the two search translation units of libmmrag.so (search.hip: slab-ring kernel for every
+// shape; search_qs.hip: query-stationary kernel for big query batches).  Internal, gfx950 only.
+#pragma once
+#include "mmrag_internal.h"
+#include "tile_dma.h"
+
+#include <limits.h>
+
+namespace mmrag_impl {
+
+constexpr float NEG_INF = -__builtin_inff();
+
+__device__ inline bool better(float s, long long r, float s2, long long r2) {
+    return s > s2 || (s == s2 && r < r2);
+}
+
+template <int K>
+struct TopList {
+    float v[K];
+    int r[K];
+    __device__ inline void init() {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            v[i] = NEG_INF;
+            r[i] = INT_MAX;
+        }
+    }
+    // full (score desc, row asc) order: for merging lists whose rows interleave
+    __device__ inline void insert_ordered(float x, int xr) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool b = x > v[j] || (x == v[j] && xr < r[j]);
+            const float nv = b ? x : v[j];
+            const float nx = b ? v[j] : x;
+            const int nr = b ? xr : r[j];
+            const int nxr = b ? r[j] : xr;
+            v[j] = nv;
+            x = nx;
+            r[j] = nr;
+            xr = nxr;
+        }
+    }
+    // insertion order == row order inside a lane, so "strictly greater" keeps the lower row on ties
+    __device__ inline void insert_strict(float x, int xr) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool b = x > v[j];
+            const float nv = b ? x : v[j];
+            const float nx = b ? v[j] : x;
+            const int nr = b ? xr : r[j];
+            const int nxr = b ? r[j] : xr;
+            v[j] = nv;
+            x = nx;
+            r[j] = nr;
+            xr = nxr;
+        }
+    }
+};
+
+struct KParams {
+    const char *q;        // [B, ld]
+    const char *corpus;   // [n, ld]
+    const uint32_t *alive_bits;
+    float *cand_s;        // [Bpad, n_lists, K]
+    int *cand_r;
+    long long n;
+    int B;
+    unsigned row_bytes;   // ld * esize, multiple of 128
+    int n_tiles;          // corpus tiles of this launch (tile height is the kernel's own)
+    int n_lists;          // list slots per query in cand_* (>= walkers)
+    int tile0;            // first corpus tile of this launch (sample pre-pass / main pass split)
+    int walkers;          // workgroups that walk the tiles, per query group (grid = walkers * query groups)
+    int share_l2;         // > 1 query group: corpus slabs are re-read by the sibling groups, keep them in L2
+    const float *thr0;    // optional [B]: a known lower bound of each query's final k-th score
+    unsigned dbg;         // timing-only switches (DBG_QS_*), reachable through the internal debug entry only
+    unsigned long long *stamps;  // DBG_QS_CLOCK: per-workgroup (shader cycles, 100 MHz ticks) of the main loop
+};
+
+// timing-only ablations of the query-stationary kernel: results are WRONG with any of them set
+constexpr unsigned DBG_QS_NO_SELECT = 16u, DBG_QS_NO_DMA = 32u, DBG_QS_NO_BARRIER = 64u, DBG_QS_DMA_L2 = 512u, DBG_QS_NO_WAIT = 1024u;
+constexpr unsigned DBG_QS_CLOCK = 256u;  // (valid results) first 16 workgroups stamp their main loop: clock under load
+constexpr unsigned DBG_QS_4_WAVES = 8u;  // (valid results) the 4-wave form of the query-stationary kernel
+
+// ---- query-stationary kernel (search_qs.hip) -------------------------------------------------------------
+// supported(): storage dtype, row bytes and list depth the kernel is instantiated for
+bool qs_supported(int dtype, unsigned row_bytes, int K);
+constexpr int QS_TILE_ROWS = 64;   // corpus rows per tile of the 4-wave form
+int qs_tile_rows(unsigned dbg);    // ... of the form the debug switches select (8-wave form: 32)
+constexpr int QS_QROWS = 256;      // queries per workgroup
+// launches over `grid_x * grid_y` workgroups of 256 threads (walkers x query groups)
+int qs_launch(int dtype, int K, const KParams &p, int grid_x, int grid_y, hipStream_t s);
+
+}  // namespace mmrag_impl

@@ -69,13 +69,11 @@ def test_full_size_properties(N, n, d, dtype, B):
     assert torch.equal(mr, r) and torch.equal(ms, s)
     hs, hr = N.merge_topk_host(torch.stack([p[0] for p in parts]).cpu(), torch.stack([p[1] for p in parts]).cpu(), k)
     assert torch.equal(hr, r.cpu()) and torch.equal(hs, s.cpu())
-    # 4. wave-layout invariance (8 vs 16 waves per workgroup): same scores, same ids
-    os.environ["MMRAG_NW8"] = "1"
-    try:
-        s8, r8 = N.cosine_topk(q, c, n, d, k)
-    finally:
-        os.environ.pop("MMRAG_NW8", None)
-    assert torch.equal(r8, r) and torch.equal(s8, s)
+    # 4. kernel invariance: the slab-ring kernel (8 and 16 waves per workgroup), with and without the sample
+    #    pre-pass, and the query-stationary kernel return the same scores and the same ids
+    for dbg in (N.DBG_NO_QS, N.DBG_NO_QS | N.DBG_8_WAVES, N.DBG_NO_PREPASS, N.DBG_NO_QS | N.DBG_NO_PREPASS):
+        s8, r8 = N.cosine_topk(q, c, n, d, k, dbg=dbg)
+        assert torch.equal(r8, r) and torch.equal(s8, s), dbg
     # 5. oracle spot check: exact fp32 scores of the returned rows, and no sampled row beats the k-th
     qs = q[:8, :d].float().cpu().numpy()
     got_rows = r[:8].cpu().numpy()

@@ -43,7 +43,7 @@ def to_dev(N, x, dtype):
     return t, stored
 
 
-def run(N, q, c, k, dtype, row_offset=0, alive=None):
+def run(N, q, c, k, dtype, row_offset=0, alive=None, dbg=0):
     qd, qs = to_dev(N, q, dtype)
     cd, cs = to_dev(N, c, dtype)
     bits = None
@@ -52,7 +52,7 @@ def run(N, q, c, k, dtype, row_offset=0, alive=None):
         idx = np.nonzero(alive)[0]
         np.bitwise_or.at(words, idx // 32, (np.uint32(1) << (idx % 32).astype(np.uint32)))
         bits = torch.from_numpy(words.view(np.int32)).to("cuda")
-    s, r = N.cosine_topk(qd, cd, c.shape[0], c.shape[1], k, row_offset=row_offset, alive_bits=bits)
+    s, r = N.cosine_topk(qd, cd, c.shape[0], c.shape[1], k, row_offset=row_offset, alive_bits=bits, dbg=dbg)
     torch.cuda.synchronize()
     es, er = O.cosine_topk(qs, cs, k, row_offset=row_offset, alive=alive)
     return s.cpu().numpy(), r.cpu().numpy(), es, er
@@ -229,3 +229,55 @@ def test_randomised_shapes_against_oracle(N):
                 assert np.all(alive[live])
         except AssertionError as e:
             raise AssertionError(f"trial {trial}: B={B} n={n} d={d} k={k} {dtype} mask={mode} off={off}") from e
+
+
+# ---- query-stationary kernel (csrc/search_qs.hip): more than 128 queries, shards of >= 256 rows per CU, fp16/bf16
+# rows of 768 / 1024 / 1536 bytes.  Every case below is also run through the slab-ring kernel (dbg=DBG_NO_QS) and
+# the two must agree bit for bit.
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,n,d", [
+    (129, 70_000, 768), (256, 66_000, 768), (200, 65_537, 512), (256, 70_001, 384), (300, 131_123, 768),
+    (1000, 140_000, 384), (256, 300_000, 768),   # the last one takes the sample pre-pass
+])
+def test_query_stationary_parity(N, dtype, B, n, d):
+    q = unit_rows(B, d, 31)
+    c = unit_rows(n, d, 32)
+    s, r, es, er = run(N, q, c, 5, dtype)
+    check(s, r, es, er)
+    qd, _ = to_dev(N, q, dtype)
+    cd, _ = to_dev(N, c, dtype)
+    for dbg in (N.DBG_NO_QS, N.DBG_NO_PREPASS, N.DBG_QS_4_WAVES, N.DBG_QS_4_WAVES | N.DBG_NO_PREPASS):
+        s2, r2 = N.cosine_topk(qd, cd, n, d, 5, dbg=dbg)
+        assert np.array_equal(r2.cpu().numpy(), r) and np.array_equal(s2.cpu().numpy(), s), dbg
+
+
+def test_query_stationary_exact_integers_and_ties(N):
+    """integer data is exact in fp16: ids must match the oracle bit for bit, ties (many) -> lower row"""
+    g = np.random.default_rng(16)
+    n, d, B = 250_000, 384, 256
+    c = g.integers(-2, 3, size=(n, d)).astype(np.float32)
+    q = g.integers(-2, 3, size=(B, d)).astype(np.float32)
+    for k in (1, 5):
+        s, r, es, er = run(N, q, c, k, torch.float16)
+        assert np.array_equal(s, es)
+        assert np.array_equal(r, er)
+        s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_QS_4_WAVES)
+        assert np.array_equal(s, es)
+        assert np.array_equal(r, er)
+
+
+def test_query_stationary_masks_offsets_ragged(N):
+    """alive bitmask (tombstones / where filters), shard row offset, ragged last tile, fewer live rows than k"""
+    n, d, B = 66_003, 768, 160
+    q = unit_rows(B, d, 41)
+    c = unit_rows(n, d, 42)
+    g = np.random.default_rng(43)
+    alive = g.random(n) < 0.5
+    for dbg in (0, N.DBG_QS_4_WAVES):
+        check(*run(N, q, c, 5, torch.float16, row_offset=1_000_000, alive=alive, dbg=dbg))
+    few = np.zeros(n, dtype=bool)
+    few[[5, 40_000, n - 1]] = True            # 3 live rows < k
+    none = np.zeros(n, dtype=bool)
+    for dbg in (0, N.DBG_QS_4_WAVES):
+        check(*run(N, q, c, 5, torch.float16, alive=few, dbg=dbg))
+        check(*run(N, q, c, 5, torch.float16, alive=none, dbg=dbg))
