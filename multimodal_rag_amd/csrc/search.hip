@@ -593,7 +593,7 @@ extern "C" {
 
 // workspace: [cand_s entries f32][cand_r entries i32][thr0 b_pad f32][sample top_s b_pad*K f32][pad][sample top_r b_pad*K i64]
 struct WsLayout {
-    size_t entries, off_r, off_thr, off_ts, off_tr, total;
+    size_t entries, off_r, off_thr, off_ts, off_tr, off_cnt, cnt_bytes, off_pub, total;
 };
 static WsLayout ws_layout(const Plan &pl) {
     WsLayout w;
@@ -602,7 +602,11 @@ static WsLayout ws_layout(const Plan &pl) {
     w.off_thr = w.off_r + w.entries * sizeof(int);
     w.off_ts = w.off_thr + (size_t)pl.b_pad * sizeof(float);
     w.off_tr = (w.off_ts + (size_t)pl.b_pad * pl.K * sizeof(float) + 15) / 16 * 16;
-    w.total = w.off_tr + (size_t)pl.b_pad * pl.K * sizeof(long long);
+    // query-stationary kernel: the per-workgroup bests of its sample pass
+    w.off_cnt = (w.off_tr + (size_t)pl.b_pad * pl.K * sizeof(long long) + 63) / 64 * 64;
+    w.cnt_bytes = 0;
+    w.off_pub = w.off_cnt + w.cnt_bytes;
+    w.total = w.off_pub + (pl.qs_ok ? (size_t)pl.b_pad * pl.grid_x * sizeof(float) : 0);
     return w;
 }
 
@@ -658,35 +662,49 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
     p.tile0 = 0;
     p.thr0 = nullptr;
     p.dbg = dbg;
-    p.stamps = ((dbg & DBG_QS_CLOCK) && workspace_bytes >= wl.total + 16 * (size_t)(pl.grid_x * pl.grid_y)) ? (unsigned long long *)((char *)workspace + wl.total) : nullptr;
+    p.stamps = ((dbg & DBG_QS_CLOCK) && workspace_bytes >= wl.total + 64 * (size_t)(pl.grid_x * pl.grid_y)) ? (unsigned long long *)((char *)workspace + wl.total) : nullptr;
     p.walkers = pl.grid_x;
     p.share_l2 = pl.grid_y > 1;
+    p.sample_best = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    // tile units: 256 rows for the slab-ring kernel, QS_TILE_ROWS for the query-stationary one
-    const bool qs = pl.qs_ok && qs_supported(dtype, p.row_bytes, pl.K);
-    const int qs_rows = qs_tile_rows(dbg);
-    const int unit = qs ? TM / qs_rows : 1;
-    const int tiles_total = qs ? (int)((n + qs_rows - 1) / qs_rows) : pl.n_tiles;
+    const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the sample's list: last slot of every query
+    if (pl.qs_ok && qs_supported(dtype, p.row_bytes, pl.K)) {
+        // query-stationary kernel.  Long shards: (1) a sample pass over the first pre_tiles * 256 rows that keeps
+        // only each workgroup's best score per query, (2) thr0[q] = K-th largest of those bests, (3) the walk over
+        // ALL rows (the sample again: it kept no candidates) with every lane's threshold warm from the first tile.
+        const int tiles = (int)((n + QS_TILE_ROWS - 1) / QS_TILE_ROWS);
+        float *thr0 = nullptr;
+        if (pl.pre_tiles > 0) {
+            KParams ks = p;
+            ks.n_tiles = pl.pre_tiles * (TM / QS_TILE_ROWS);
+            ks.sample_best = (float *)((char *)workspace + wl.off_pub);
+            if (int st = qs_launch(dtype, pl.K, ks, pl.grid_x, pl.grid_y, s)) return st;
+            thr0 = (float *)((char *)workspace + wl.off_thr);
+            if (int st = qs_seed_thresholds(pl.K, ks.sample_best, pl.grid_x, pl.b_pad, thr0, s)) return st;
+        }
+        p.n_tiles = tiles;
+        p.thr0 = thr0;
+        if (int st = qs_launch(dtype, pl.K, p, pl.grid_x, pl.grid_y, s)) return st;
+        MMRAG_CHECK_HIP(hipGetLastError());
+        return MMRAG_OK;
+    }
     auto run = [&](int tile0, int n_tiles, int grid_x, const float *thr0) -> int {
         KParams kp = p;
         kp.tile0 = tile0;
         kp.n_tiles = n_tiles;
         kp.thr0 = thr0;
-        if (qs) return qs_launch(dtype, pl.K, kp, grid_x, pl.grid_y, s);
         Plan lp = pl;
         lp.grid_x = grid_x;
         if (dtype == MMRAG_F32) return dispatch_main<MMRAG_F32>(lp, kp, s);
         if (dtype == MMRAG_F16) return dispatch_main<MMRAG_F16>(lp, kp, s);
         return dispatch_main<MMRAG_BF16>(lp, kp, s);
     };
-    const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the sample's list: last slot of every query
     if (pl.pre_tiles > 0) {
-        // 1. sample pre-pass over the first pre_tiles * 256 rows, spread over the walkers
+        // 1. sample pre-pass over the first pre_tiles tiles, one per workgroup
         float *thr0 = (float *)((char *)workspace + wl.off_thr);
         float *top_s = (float *)((char *)workspace + wl.off_ts);
         long long *top_r = (long long *)((char *)workspace + wl.off_tr);
-        int pre = pl.pre_tiles * unit;
-        if (qs && ((dbg >> 14) & 3u)) pre = pl.grid_x * (int)((dbg >> 14) & 3u);  // A/B: sample tiles per walker
+        const int pre = pl.pre_tiles;
         const int pre_grid = pre < pl.grid_x ? pre : pl.grid_x;
         if (int st = run(0, pre, pre_grid, nullptr)) return st;
         MMRAG_CHECK_HIP(hipGetLastError());
@@ -696,7 +714,7 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
                           top_r, s, thr0, p.cand_s + seed_off, p.cand_r + seed_off, (long long)pl.n_lists * pl.K);
         MMRAG_CHECK_HIP(hipGetLastError());
         // 4. main pass over the remaining tiles, selection armed with the sample thresholds
-        if (int st = run(pre, tiles_total - pre, pl.grid_x, thr0)) return st;
+        if (int st = run(pre, pl.n_tiles - pre, pl.grid_x, thr0)) return st;
     } else {
         if (pl.n_lists > pl.grid_x) {
             // (debug: pre-pass switched off) the sample's list slot exists but nothing fills it
@@ -704,7 +722,7 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
             fill_seed_empty_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(
                 p.cand_s + seed_off, p.cand_r + seed_off, (long long)pl.n_lists * pl.K, pl.K, total);
         }
-        if (int st = run(0, tiles_total, pl.grid_x, nullptr)) return st;
+        if (int st = run(0, pl.n_tiles, pl.grid_x, nullptr)) return st;
     }
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;

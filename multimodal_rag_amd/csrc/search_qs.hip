@@ -98,6 +98,37 @@ __device__ __forceinline__ void qs_kstep(f32x16_t &c00, f32x16_t &c01, f32x16_t 
     }
 }
 
+// K-th largest of the (up to) 256 values a wave holds four per lane; every lane gets the result.  Used to turn the
+// per-workgroup best scores of one query into a threshold: the values are scores of distinct rows, so K rows reach it.
+template <int K>
+__device__ inline float wave_kth_largest(float a, float b, float c, float d, int lane) {
+    auto ce = [](float &x, float &y) {
+        const float hi = fmaxf(x, y), lo = fminf(x, y);
+        x = hi;
+        y = lo;
+    };
+    ce(a, b);
+    ce(c, d);
+    ce(a, c);
+    ce(b, d);
+    ce(b, c);  // a >= b >= c >= d
+    float res = NEG_INF;
+    for (int r = 0; r < K; ++r) {
+        float m = a;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        res = m;
+        const unsigned long long owners = __builtin_amdgcn_ballot_w64(a == m);
+        if (owners != 0ull && lane == (int)__builtin_ctzll(owners)) {  // one lane gives up its head
+            a = b;
+            b = c;
+            c = d;
+            d = NEG_INF;
+        }
+    }
+    return res;
+}
+
 template <int DT, int NK, int K, bool NT>
 __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -119,14 +150,16 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
     static_assert((G - 1) * SLABB + 32 * SLAB < 65536, "ds_read immediate offset");
 
     __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE + LISTS];
-    float *lv = (float *)(smem + NST * STAGE);               // [K][2][256] scores
-    int *lr = (int *)(smem + NST * STAGE + LISTS / 2);       // [K][2][256] rows
+    // per-lane top-K lists: entry e of thread t at [e][t], e = qb * 2K + i (scores) / qb * 2K + K + i (rows):
+    // ONE base address register per lane, everything else in the instruction's immediate offset
+    float *lists = (float *)(smem + NST * STAGE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31;
     const int h = lane >> 5;
+    const unsigned long long t_entry = (p.dbg & DBG_QS_CLOCK) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     const unsigned RBy = p.row_bytes;
     const int walkers = p.walkers;
@@ -134,32 +167,32 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
     const int by = (int)blockIdx.x / walkers;
     const int q0 = by * QS_QROWS;
     const int my_tiles = (p.n_tiles - bx + walkers - 1) / walkers;
-    const int n_items = my_tiles * SPT;
 
     // ---- corpus DMA: per-lane source offsets of this wave's RB pieces of a slab -----------------------
-    unsigned c_off[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int row = (wave * RB + i) * 8 + (lane >> 3);
-        c_off[i] = (unsigned)row * RBy + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    // piece i = 1 is 8 rows below piece 0: same lanes, row + 8 flips bit 2 of the swizzle term
+    unsigned c_off0;
+    {
+        const int row = (wave * RB) * 8 + (lane >> 3);
+        c_off0 = (unsigned)row * RBy + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
+    auto c_off = [&](int i) -> unsigned { return i == 0 ? c_off0 : (c_off0 ^ 64u) + 8u * RBy; };
     // A ring stage is refilled piece by piece, one 1 KiB piece after every other k-step: four waves alone on
     // their SIMDs pay every DMA instruction with matrix-pipe time, and a burst of eight backs up in the
     // texture-address queue.  `fill` describes the stage being refilled; stages past the end of this
     // workgroup's walk are refilled through a zero-length descriptor (nothing is fetched), so the instruction
     // stream and the vmcnt arithmetic have no tail cases.
+    const int n_items = my_tiles * SPT;
+    auto tile_at = [&](int pos) -> long long { return (long long)p.tile0 + bx + (long long)pos * walkers; };
     int is_tile = 0, is_sg = 0, is_item = 0;
     __amdgpu_buffer_rsrc_t fill_rsrc;
     char *fill_lds;
     int fill_k0;
     auto next_fill = [&](int buf) {
-        const long long tile = (long long)p.tile0 + bx + (long long)is_tile * walkers;
-        const long long row0 = (p.dbg & DBG_QS_DMA_L2) ? (long long)bx * R : tile * R;
+        const bool real = is_item < n_items && !(p.dbg & DBG_QS_NO_DMA);
+        const long long row0 = real ? ((p.dbg & DBG_QS_DMA_L2) ? (long long)bx * R : tile_at(is_tile) * R) : 0;
         const long long rows_left = p.n - row0;
-        unsigned c_bytes = (unsigned)((rows_left < R ? rows_left : (long long)R) * (long long)RBy);
-        if (is_item >= n_items || (p.dbg & DBG_QS_NO_DMA)) c_bytes = 0;
-        fill_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(p.corpus + (size_t)(is_item < n_items ? row0 : 0) * RBy), 0, c_bytes, 0x00020000);
+        const unsigned c_bytes = real ? (unsigned)((rows_left < R ? rows_left : (long long)R) * (long long)RBy) : 0u;
+        fill_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.corpus + (size_t)row0 * RBy), 0, c_bytes, 0x00020000);
         fill_lds = smem + buf * STAGE + wave * (RB * 1024);
         fill_k0 = is_sg * (G * SLAB);
         ++is_item;
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         constexpr int g = PI / RB, i = PI % RB;
         // NT: the corpus is read once, by this CU only: non-temporal.  Several query groups share the tiles: keep
         // them in L2 for the siblings.
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(fill_rsrc, (lds_ptr_t)(fill_lds + g * SLABB + i * 1024), 16, c_off[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fill_rsrc, (lds_ptr_t)(fill_lds + g * SLABB + i * 1024), 16, c_off(i),
                                                  fill_k0 + g * SLAB, 0, NT ? 2 : 0);
     };
     auto issue_all = [&]() {
@@ -208,24 +241,23 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         // padding query slot: its all-zero scores must never open the insertion path
         thr[qb] = !live ? INFINITY : (p.thr0 != nullptr ? p.thr0[qrow] : NEG_INF);
     }
+    float *const my_lists = lists + tid;
+    auto lst_v = [&](int qb, int i) -> float & { return my_lists[(qb * 2 * K + i) * QS_QROWS]; };
+    auto lst_r = [&](int qb, int i) -> int & { return *(int *)&my_lists[(qb * 2 * K + K + i) * QS_QROWS]; };
 #pragma unroll
-    for (int i = 0; i < K; ++i)
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            lv[(i * 2 + qb) * QS_QROWS + tid] = NEG_INF;
-            lr[(i * 2 + qb) * QS_QROWS + tid] = INT_MAX;
+        for (int i = 0; i < K; ++i) {
+            lst_v(qb, i) = NEG_INF;
+            lst_r(qb, i) = INT_MAX;
         }
 
-    for (int st = 0; st < NST; ++st) {
-        next_fill(st);
-        issue_all();
-    }
-
-    // ---- fragment addresses: lane part; the ring stage's base is added per stage --------------------------
+    // ---- fragment addresses: lane part; the ring stage's base is added per stage.  ONE lane constant: k-step m of
+    // a slab reads chunk (2m + h) ^ sw of row r32, and (2m + h) ^ sw == (h ^ sw) ^ 2m, so the four k-steps of a slab
+    // sit at byte offsets base ^ 0, ^ 32, ^ 64, ^ 96 -- registers go to Q, not to addresses.
     const int sw = (r32 >> 1) & 7;
-    unsigned lane_off[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) lane_off[m] = (unsigned)(r32 * SLAB + ((2 * m + h) ^ sw) * 16);
+    const unsigned lane_off0 = (unsigned)(r32 * SLAB + ((h ^ sw) * 16));
+    auto lane_off = [&](int m) -> unsigned { return lane_off0 ^ (unsigned)(32 * m); };
     const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
 
     f32x16_t c00, c01, c10, c11;  // [row block][query block]
@@ -241,20 +273,26 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         }
     };
 
-    // ---- selection: lane-local, lists in LDS, entered only when some lane's score reaches its threshold ---
-    auto select = [&](const int qb, const f32x16_t &lo, const f32x16_t &hi, const int row_base) {
+    auto tile_max = [&](const f32x16_t &lo, const f32x16_t &hi) -> float {
         float mx = lo[0];
 #pragma unroll
         for (int j = 1; j < 16; ++j) mx = fmaxf(mx, lo[j]);
 #pragma unroll
         for (int j = 0; j < 16; ++j) mx = fmaxf(mx, hi[j]);
+        return mx;
+    };
+    float best[2] = {NEG_INF, NEG_INF};  // sample pass only
+
+    // ---- selection: lane-local, lists in LDS, entered only when some lane's score reaches its threshold ---
+    auto select = [&](const int qb, const f32x16_t &lo, const f32x16_t &hi, const int row_base) {
+        const float mx = tile_max(lo, hi);
         float t = thr[qb];
         if (__builtin_amdgcn_ballot_w64(mx >= t) == 0ull) return;
         TopList<K> L;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            L.v[i] = lv[(i * 2 + qb) * QS_QROWS + tid];
-            L.r[i] = lr[(i * 2 + qb) * QS_QROWS + tid];
+            L.v[i] = lst_v(qb, i);
+            L.r[i] = lst_r(qb, i);
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
@@ -283,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         thr[qb] = fmaxf(t, u);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            lv[(i * 2 + qb) * QS_QROWS + tid] = L.v[i];
-            lr[(i * 2 + qb) * QS_QROWS + tid] = L.r[i];
+            lst_v(qb, i) = L.v[i];
+            lst_r(qb, i) = L.r[i];
         }
     };
 
@@ -298,11 +336,15 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         t0r = __builtin_amdgcn_s_memrealtime();
     }
     if (my_tiles > 0) {
+        for (int st = 0; st < NST; ++st) {
+            next_fill(st);
+            issue_all();
+        }
         FT fa0, fa1, fb0, fb1;  // A fragments of the current / next k-step (two row blocks each)
         wait_vmcnt<(NST - 1) * PPS>();
         __builtin_amdgcn_s_barrier();
         {
-            const char *st = smem + lane_off[0];
+            const char *st = smem + lane_off(0);
             fa0 = *(const FT *)(st);
             fa1 = *(const FT *)(st + 32 * SLAB);
         }
@@ -320,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
                         const bool last = g == G - 1 && m == 3;        // next step opens the next stage
                         const int ng = last ? 0 : (m == 3 ? g + 1 : g);
                         const int nm = (m + 1) & 3;
-                        const unsigned addr = (last ? st_nxt : st_cur) + lane_off[nm];
+                        const unsigned addr = (last ? st_nxt : st_cur) + lane_off(nm);
                         auto step = [&](auto ng_c, auto qa_c, FT &x0, FT &x1, FT &y0, FT &y1) {
                             constexpr int NG = decltype(ng_c)::value;
                             constexpr bool QA = decltype(qa_c)::value;
@@ -366,8 +408,7 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
                 }
             }
             asm volatile("s_nop 15\n\ts_nop 7");  // last MFMA's D -> VALU readers
-            const long long tile = (long long)p.tile0 + bx + (long long)ti * walkers;
-            const long long row0 = tile * R;
+            const long long row0 = tile_at(ti) * R;
             if (row0 + R > p.n || p.alive_bits != nullptr) {
                 const long long left = p.n - row0;  // >= 1
                 unsigned m0 = left >= 32 ? 0xffffffffu : ((1u << (int)left) - 1u);
@@ -384,7 +425,11 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
                 strike(c10, c11, m1);
             }
             const int row_base = (int)row0 + 4 * h;
-            if (!(p.dbg & DBG_QS_NO_SELECT)) {
+            if (p.sample_best != nullptr) {
+                // sample pass: only the best score of each query matters (K workgroups' bests bound the K-th score)
+                best[0] = fmaxf(best[0], tile_max(c00, c10));
+                best[1] = fmaxf(best[1], tile_max(c01, c11));
+            } else if (!(p.dbg & DBG_QS_NO_SELECT)) {
                 select(0, c00, c10, row_base);
                 select(1, c01, c11, row_base);
             } else {
@@ -392,25 +437,36 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
             }
         }
     }
-
     if ((p.dbg & DBG_QS_CLOCK) && p.stamps != nullptr && tid == 0) {
-        p.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-        p.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        p.stamps[8 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        p.stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        p.stamps[8 * blockIdx.x + 2] = t0r - t_entry;
+        p.stamps[8 * blockIdx.x + 3] = t_entry;
+    }
+    if (p.sample_best != nullptr) {
+        // sample pass: best[q][bx] for the threshold kernel; padding queries publish -inf
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float m = fmaxf(best[qb], __shfl_xor(best[qb], 32));
+            const int q = q0 + wave * 64 + qb * 32 + r32;
+            if (h == 0) p.sample_best[(size_t)q * walkers + bx] = q < p.B ? m : NEG_INF;
+        }
+        return;
     }
     // ---- merge the two half-wave lists of every query, write ONE list per query per workgroup ------------
     __syncthreads();
     if (q0 + tid < p.B) {
         const int w = tid >> 6, qb = (tid >> 5) & 1, r = tid & 31;
-        const int ta = w * 64 + r, tb = ta + 32;
+        const float *la = lists + w * 64 + r + (qb * 2 * K) * QS_QROWS, *lb = la + 32;
         TopList<K> m;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            m.v[i] = lv[(i * 2 + qb) * QS_QROWS + ta];
-            m.r[i] = lr[(i * 2 + qb) * QS_QROWS + ta];
+            m.v[i] = la[i * QS_QROWS];
+            m.r[i] = __float_as_int(la[(K + i) * QS_QROWS]);
         }
         for (int i = 0; i < K; ++i) {
-            const float x = lv[(i * 2 + qb) * QS_QROWS + tb];
-            const int xr = lr[(i * 2 + qb) * QS_QROWS + tb];
+            const float x = lb[i * QS_QROWS];
+            const int xr = __float_as_int(lb[(K + i) * QS_QROWS]);
             if (xr == INT_MAX || !better(x, xr, m.v[K - 1], m.r[K - 1])) break;
             m.insert_ordered(x, xr);
         }
@@ -420,306 +476,41 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
             p.cand_s[base + i] = m.v[i];
             p.cand_r[base + i] = m.r[i];
         }
+        if (bx == 0 && p.n_lists > walkers) {
+            // the list slot the two-launch plan keeps for its sample pass: nothing to put there
+            const size_t seed = ((size_t)(q0 + tid) * p.n_lists + (p.n_lists - 1)) * K;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                p.cand_s[seed + i] = NEG_INF;
+                p.cand_r[seed + i] = INT_MAX;
+            }
+        }
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// ----------------------------------------------------------------------------------------------------------
-// 8-wave form: two waves per SIMD, 256 registers each.  A wave owns ONE 32-query block (48 Q fragments = 192
-// registers at d=768) and the tile is 32 corpus rows, so a k-step is one A-fragment read and one MFMA.  Every A
-// fragment feeds one MFMA instead of two (twice the LDS read traffic of the 4-wave form, ~50 % of the LDS read
-// rate), but the partner wave's MFMAs cover this wave's DMA issue, selection epilogue, LDS latency and barrier
-// waits.  A fragments are read PD k-steps ahead (counted lgkmcnt: LDS operations return in order).
-// ----------------------------------------------------------------------------------------------------------
-constexpr int QS8_TILE_ROWS = 32;
-
-#define MMRAG_QS8_KSTEP(MNEMONIC, QC, CIN)                                                                   \
-    asm volatile("ds_read_b128 %1, %4 offset:%5\n\t" MNEMONIC " %0, %2, %3, " CIN "\n\t"                     \
-                 "s_waitcnt lgkmcnt(%6)"                                                                     \
-                 : "+v"(c), "=&v"(nxt)                                                                       \
-                 : "v"(a), QC(q), "v"(addr), "i"(OFF), "i"(WAIT))
-
-template <int DT, bool QA, bool FIRST, int OFF, int WAIT, typename FT>
-__device__ __forceinline__ void qs8_kstep(f32x16_t &c, const FT a, const FT q, FT &nxt, const unsigned addr) {
-    if constexpr (FIRST) {
-        static_assert(QA, "the first k-step's Q fragment lives in the accumulator file");
-        if constexpr (DT == MMRAG_F16) MMRAG_QS8_KSTEP("v_mfma_f32_32x32x16_f16", "a", "0");
-        else MMRAG_QS8_KSTEP("v_mfma_f32_32x32x16_bf16", "a", "0");
-    } else if constexpr (DT == MMRAG_F16) {
-        if constexpr (QA) MMRAG_QS8_KSTEP("v_mfma_f32_32x32x16_f16", "a", "%0");
-        else MMRAG_QS8_KSTEP("v_mfma_f32_32x32x16_f16", "v", "%0");
-    } else {
-        if constexpr (QA) MMRAG_QS8_KSTEP("v_mfma_f32_32x32x16_bf16", "a", "%0");
-        else MMRAG_QS8_KSTEP("v_mfma_f32_32x32x16_bf16", "v", "%0");
+// thr0[q] = K-th largest of the `walkers` per-workgroup bests of query q (scores of distinct rows of the sample, so
+// at least K rows of the shard reach it: a valid lower bound of the final K-th score).  One wave per query.
+template <int K>
+__global__ __launch_bounds__(256) void qs_seed_thr_kernel(const float *__restrict__ best, int walkers, int n_queries,
+                                                          float *__restrict__ thr0) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n_queries) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int w = lane + 64 * j;
+        v[j] = w < walkers ? best[(size_t)q * walkers + w] : NEG_INF;
     }
+    const float t = wave_kth_largest<K>(v[0], v[1], v[2], v[3], lane);
+    if (lane == 0) thr0[q] = t;
 }
 
-// wait until at most `items` later ring stages (LOADS wave-instructions each) are outstanding
-template <int LOADS, int MAXITEMS>
-__device__ inline void wait_stages(int items) {
-    if constexpr (MAXITEMS > 0) {
-        if (items >= MAXITEMS) {
-            wait_vmcnt<MAXITEMS * LOADS>();
-            return;
-        }
-        wait_stages<LOADS, MAXITEMS - 1>(items);
-    } else {
-        wait_vmcnt<0>();
-    }
-}
-
-template <int DT, int NK, int K, int NBUF>
-__global__ __launch_bounds__(512, 2) void cosine_topk_qs8_kernel(const KParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    using FT = typename Frag<DT>::T;
-    constexpr int R = QS8_TILE_ROWS;
-    constexpr int SLABB = R * SLAB;                   // one K-slab of a tile: 4 KiB = 4 DMA pieces
-    constexpr int G = NK % 4 == 0 ? 4 : NK;           // K-slabs per ring stage (even: 4 G pieces over 8 waves)
-    static_assert(G % 2 == 0 && NK % G == 0, "stage shape");
-    constexpr int SPT = NK / G;                       // ring stages per tile
-    constexpr int STAGE = G * SLABB;
-    constexpr int PPS = G / 2;                        // 1 KiB DMA pieces per wave per stage
-    constexpr int KS = G * 4;                         // k-steps per stage
-    constexpr int KST = NK * 4;                       // k-steps per tile = Q fragments per wave
-    // NBUF A-fragment registers rotate over the tile's k-steps
-    constexpr int PD = NBUF - 1;                      // read-ahead distance in k-steps
-    constexpr int QA_STEPS = KST < 32 ? KST : 32;     // Q fragments kept in the accumulator file (128 registers)
-    constexpr int LISTS = qs_lists_bytes(K);
-    constexpr int NST_FIT = (160 * 1024 - LISTS) / STAGE;
-    constexpr int NST = NST_FIT > 8 ? 8 : NST_FIT;
-    static_assert(NST >= 3 && (NST - 1) * PPS <= 56, "ring");
-    static_assert(KST % NBUF == 0 && PD < KS, "fragment rotation");
-
-    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE + LISTS];
-    float *lv = (float *)(smem + NST * STAGE);               // [K][512] scores
-    int *lr = (int *)(smem + NST * STAGE + LISTS / 2);       // [K][512] rows
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r32 = lane & 31;
-    const int h = lane >> 5;
-
-    const unsigned RBy = p.row_bytes;
-    const int walkers = p.walkers;
-    const int bx = (int)blockIdx.x % walkers;
-    const int by = (int)blockIdx.x / walkers;
-    const int q0 = by * QS_QROWS;
-    const int my_tiles = (p.n_tiles - bx + walkers - 1) / walkers;
-    const int n_items = my_tiles * SPT;
-
-    // ---- corpus DMA: a stage is 4 G pieces of 8 rows x 128 B; wave w moves pieces w, w + 8, ... --------------
-    unsigned c_off;
-    {
-        const int row = (wave & 3) * 8 + (lane >> 3);
-        c_off = (unsigned)row * RBy + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
-    }
-    int is_tile = 0, is_sg = 0;
-    auto issue = [&](int buf) {
-        const long long tile = (long long)p.tile0 + bx + (long long)is_tile * walkers;
-        const long long row0 = (p.dbg & DBG_QS_DMA_L2) ? (long long)bx * R : tile * R;
-        const long long rows_left = p.n - row0;
-        const unsigned c_bytes = (unsigned)((rows_left < R ? rows_left : (long long)R) * (long long)RBy);
-        const __amdgpu_buffer_rsrc_t rsrc_c =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(p.corpus + (size_t)row0 * RBy), 0, c_bytes, 0x00020000);
-        char *st = smem + buf * STAGE + wave * 1024;      // piece w of the stage = slab w / 4, rows 8 (w % 4) ...
-        const int k0 = (is_sg * G + (wave >> 2)) * SLAB;
-        if (p.dbg & DBG_QS_NO_DMA) {
-        } else if (p.share_l2) {
-#pragma unroll
-            for (int i = 0; i < PPS; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + i * 8192), 16, c_off, k0 + i * 2 * SLAB, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < PPS; ++i)  // read once, by this CU only: non-temporal
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(st + i * 8192), 16, c_off, k0 + i * 2 * SLAB, 0, 2);
-        }
-        if (++is_sg == SPT) {
-            is_sg = 0;
-            ++is_tile;
-        }
-    };
-
-    // ---- the stationary operand: this wave's 32 queries, all of K, as B fragments --------------------------
-    FT qf[KST];
-    float thr;
-    {
-        const int qrow = q0 + wave * 32 + r32;
-        const bool live = qrow < p.B;
-        const char *src = p.q + (size_t)(live ? qrow : 0) * RBy + h * 16;
-#pragma unroll
-        for (int s = 0; s < KST; ++s) {
-            FT v = *(const FT *)(src + s * 32);
-            if (!live) v = FT{};
-            qf[s] = v;
-        }
-        // padding query slot: its all-zero scores must never open the insertion path
-        thr = !live ? INFINITY : (p.thr0 != nullptr ? p.thr0[qrow] : NEG_INF);
-    }
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        lv[i * 512 + tid] = NEG_INF;
-        lr[i * 512 + tid] = INT_MAX;
-    }
-
-    int issued = 0;
-    for (; issued < NST && issued < n_items; ++issued) issue(issued);
-
-    const int sw = (r32 >> 1) & 7;
-    unsigned lane_off[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) lane_off[m] = (unsigned)(r32 * SLAB + ((2 * m + h) ^ sw) * 16);
-    const unsigned smem_base = (unsigned)(size_t)(lds_ptr_t)smem;
-
-    f32x16_t c0;  // the tile's 32 rows x this wave's 32 queries
-
-    auto select = [&](const int row_base) {
-        float mx = c0[0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, c0[j]);
-        float t = thr;
-        if (__builtin_amdgcn_ballot_w64(mx >= t) == 0ull) return;
-        TopList<K> L;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            L.v[i] = lv[i * 512 + tid];
-            L.r[i] = lr[i * 512 + tid];
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float a0 = c0[4 * g], a1 = c0[4 * g + 1], a2 = c0[4 * g + 2], a3 = c0[4 * g + 3];
-            if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) >= t) != 0ull) {
-#pragma clang loop unroll(disable)
-                for (int i = 0; i < 4; ++i) {
-                    const float s = i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
-                    const bool pass = s >= t;
-                    if (__builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                        L.insert_strict(pass ? s : NEG_INF, row_base + i + 8 * g);
-                        t = fmaxf(t, L.v[K - 1]);
-                    }
-                }
-            }
-        }
-        // k-th best of the union of the two half-wave lists of this query: a lower bound of the final k-th score
-        float u = fmaxf(L.v[K - 1], __shfl_xor(L.v[K - 1], 32));
-#pragma unroll
-        for (int i = 0; i + 1 < K; ++i) u = fmaxf(u, fminf(L.v[i], __shfl_xor(L.v[K - 2 - i], 32)));
-        thr = fmaxf(t, u);
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            lv[i * 512 + tid] = L.v[i];
-            lr[i * 512 + tid] = L.r[i];
-        }
-    };
-
-    // ---- main loop: one software pipeline over k-steps; step s reads the A fragment of step s + PD.  The stage
-    // hand-over (all LDS reads of the stage back, counted vmcnt for the next stage's DMA, s_barrier, refill of the
-    // drained stage) follows the step that issued the stage's last read. ------------------------------------------
-    unsigned long long t0c = 0, t0r = 0;
-    if (p.dbg & DBG_QS_CLOCK) {
-        t0c = __builtin_amdgcn_s_memtime();
-        t0r = __builtin_amdgcn_s_memrealtime();
-    }
-    if (my_tiles > 0) {
-        FT fb[NBUF];
-        wait_stages<PPS, NST - 1>(issued - 1);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int j = 0; j < PD; ++j) fb[j] = *(const FT *)(smem + (j >> 2) * SLABB + lane_off[j & 3]);
-        for (int ti = 0; ti < my_tiles; ++ti) {
-#pragma unroll
-            for (int sg = 0; sg < SPT; ++sg) {
-                const int it = ti * SPT + sg;
-                const unsigned st_cur = smem_base + (unsigned)((it % NST) * STAGE);
-                const unsigned st_nxt = smem_base + (unsigned)(((it + 1) % NST) * STAGE);
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const int ks = sg * KS + j;                // this step's Q fragment
-                    const int tj = (j + PD) % KS;              // the step read now, inside its stage
-                    const bool nxt = j + PD >= KS;
-                    const unsigned addr = (nxt ? st_nxt : st_cur) + lane_off[tj & 3];
-                    auto step = [&](auto ng_c, auto qa_c) {
-                        constexpr int NG = decltype(ng_c)::value;
-                        constexpr bool QA = decltype(qa_c)::value;
-                        if (ks == 0)
-                            qs8_kstep<DT, true, true, NG * SLABB, PD - 1, FT>(c0, fb[ks % NBUF], qf[ks],
-                                                                           fb[(ks + PD) % NBUF], addr);
-                        else
-                            qs8_kstep<DT, QA, false, NG * SLABB, PD - 1, FT>(c0, fb[ks % NBUF], qf[ks],
-                                                                          fb[(ks + PD) % NBUF], addr);
-                    };
-                    auto with_ng = [&](auto qa_c) {
-                        const int ng = tj >> 2;
-                        if (ng == 0) step(std::integral_constant<int, 0>{}, qa_c);
-                        else if (ng == 1) step(std::integral_constant<int, 1>{}, qa_c);
-                        else if (ng == 2) step(std::integral_constant<int, 2>{}, qa_c);
-                        else if (ng == 3) step(std::integral_constant<int, 3>{}, qa_c);
-                        else if (ng == 4) step(std::integral_constant<int, 4>{}, qa_c);
-                        else step(std::integral_constant<int, 5>{}, qa_c);
-                    };
-                    if (ks < QA_STEPS) with_ng(std::true_type{});
-                    else with_ng(std::false_type{});
-                    if (j == KS - 1 - PD) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (!(p.dbg & DBG_QS_NO_WAIT)) wait_stages<PPS, NST - 2>(issued - it - 2);
-                        if (!(p.dbg & DBG_QS_NO_BARRIER)) __builtin_amdgcn_s_barrier();
-                        if (issued < n_items) {
-                            issue(it % NST);
-                            ++issued;
-                        }
-                    }
-                }
-            }
-            asm volatile("s_nop 15\n\ts_nop 7");  // last MFMA's D -> VALU readers
-            const long long tile = (long long)p.tile0 + bx + (long long)ti * walkers;
-            const long long row0 = tile * R;
-            if (row0 + R > p.n || p.alive_bits != nullptr) {
-                const long long left = p.n - row0;  // >= 1
-                unsigned m0 = left >= 32 ? 0xffffffffu : ((1u << (int)left) - 1u);
-                if (p.alive_bits != nullptr) {
-                    // scalar load (wave-uniform word): a vector load here would make hipcc drain vmcnt, i.e. the
-                    // whole DMA ring, once per tile
-                    typedef const __attribute__((address_space(4))) uint32_t *scalar_words_t;
-                    m0 &= ((scalar_words_t)p.alive_bits)[row0 >> 5];
-                }
-                const unsigned mh = m0 >> (4 * h);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) c0[j] = ((mh >> ((j & 3) + 8 * (j >> 2))) & 1u) ? c0[j] : NEG_INF;
-            }
-            if (!(p.dbg & DBG_QS_NO_SELECT)) select((int)row0 + 4 * h);
-            else asm volatile("" ::"v"(c0));
-        }
-    }
-
-    if ((p.dbg & DBG_QS_CLOCK) && p.stamps != nullptr && tid == 0) {
-        p.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-        p.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
-    }
-    // ---- merge the two half-wave lists of every query, write ONE list per query per workgroup ------------
-    __syncthreads();
-    if (tid < QS_QROWS && q0 + tid < p.B) {
-        const int w = tid >> 5, r = tid & 31;
-        const int ta = w * 64 + r, tb = ta + 32;
-        TopList<K> m;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            m.v[i] = lv[i * 512 + ta];
-            m.r[i] = lr[i * 512 + ta];
-        }
-        for (int i = 0; i < K; ++i) {
-            const float x = lv[i * 512 + tb];
-            const int xr = lr[i * 512 + tb];
-            if (xr == INT_MAX || !better(x, xr, m.v[K - 1], m.r[K - 1])) break;
-            m.insert_ordered(x, xr);
-        }
-        const size_t base = ((size_t)(q0 + tid) * p.n_lists + bx) * K;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            p.cand_s[base + i] = m.v[i];
-            p.cand_r[base + i] = m.r[i];
-        }
-    }
-#endif  // __HIP_DEVICE_COMPILE__
+int qs_seed_thresholds(int K, const float *best, int walkers, int n_queries, float *thr0, hipStream_t s) {
+    if (K != 5 || walkers > 256) return MMRAG_EUNSUPPORTED;
+    qs_seed_thr_kernel<5><<<(n_queries + 3) / 4, 256, 0, s>>>(best, walkers, n_queries, thr0);
+    return MMRAG_OK;
 }
 
 bool qs_supported(int dtype, unsigned row_bytes, int K) {
@@ -731,21 +522,6 @@ bool qs_supported(int dtype, unsigned row_bytes, int K) {
 
 template <int DT, int K>
 static int qs_launch_nk(const KParams &p, int grid, hipStream_t s) {
-    if (!(p.dbg & DBG_QS_4_WAVES)) {
-        const unsigned var = (p.dbg >> 12) & 3u;  // A/B: read-ahead depth
-        switch (p.row_bytes / SLAB) {
-            case 6: cosine_topk_qs8_kernel<DT, 6, K, 4><<<grid, 512, 0, s>>>(p); break;
-            case 8: cosine_topk_qs8_kernel<DT, 8, K, 4><<<grid, 512, 0, s>>>(p); break;
-            case 12:
-                if (var == 1) cosine_topk_qs8_kernel<DT, 12, K, 3><<<grid, 512, 0, s>>>(p);
-                else if (var == 2) cosine_topk_qs8_kernel<DT, 12, K, 6><<<grid, 512, 0, s>>>(p);
-                else if (var == 3) cosine_topk_qs8_kernel<DT, 12, K, 8><<<grid, 512, 0, s>>>(p);
-                else cosine_topk_qs8_kernel<DT, 12, K, 4><<<grid, 512, 0, s>>>(p);
-                break;
-            default: return MMRAG_EUNSUPPORTED;
-        }
-        return MMRAG_OK;
-    }
     const bool nt = !p.share_l2;
     switch (p.row_bytes / SLAB) {
         case 6:
@@ -764,8 +540,6 @@ static int qs_launch_nk(const KParams &p, int grid, hipStream_t s) {
     }
     return MMRAG_OK;
 }
-
-int qs_tile_rows(unsigned dbg) { return (dbg & DBG_QS_4_WAVES) ? QS_TILE_ROWS : QS8_TILE_ROWS; }
 
 int qs_launch(int dtype, int K, const KParams &p, int grid_x, int grid_y, hipStream_t s) {
     KParams kp = p;

@@ -74,20 +74,23 @@ struct KParams {
     const float *thr0;    // optional [B]: a known lower bound of each query's final k-th score
     unsigned dbg;         // timing-only switches (DBG_QS_*), reachable through the internal debug entry only
     unsigned long long *stamps;  // DBG_QS_CLOCK: per-workgroup (shader cycles, 100 MHz ticks) of the main loop
+    float *sample_best;   // query-stationary kernel, sample pass: [b_pad][walkers] best score per query per workgroup
+                          // (no candidate lists are written); null = a normal pass
 };
 
 // timing-only ablations of the query-stationary kernel: results are WRONG with any of them set
 constexpr unsigned DBG_QS_NO_SELECT = 16u, DBG_QS_NO_DMA = 32u, DBG_QS_NO_BARRIER = 64u, DBG_QS_DMA_L2 = 512u, DBG_QS_NO_WAIT = 1024u;
 constexpr unsigned DBG_QS_CLOCK = 256u;  // (valid results) first 16 workgroups stamp their main loop: clock under load
-constexpr unsigned DBG_QS_4_WAVES = 8u;  // (valid results) the 4-wave form of the query-stationary kernel
 
 // ---- query-stationary kernel (search_qs.hip) -------------------------------------------------------------
 // supported(): storage dtype, row bytes and list depth the kernel is instantiated for
 bool qs_supported(int dtype, unsigned row_bytes, int K);
-constexpr int QS_TILE_ROWS = 64;   // corpus rows per tile of the 4-wave form
-int qs_tile_rows(unsigned dbg);    // ... of the form the debug switches select (8-wave form: 32)
+constexpr int QS_TILE_ROWS = 64;   // corpus rows per tile
 constexpr int QS_QROWS = 256;      // queries per workgroup
 // launches over `grid_x * grid_y` workgroups of 256 threads (walkers x query groups)
 int qs_launch(int dtype, int K, const KParams &p, int grid_x, int grid_y, hipStream_t s);
+// thr0[q] = K-th largest of best[q][0 .. walkers): the threshold a sample pass yields
+int qs_seed_thresholds(int K, const float *best, int walkers, int n_queries, float *thr0, hipStream_t s);
+
 
 }  // namespace mmrag_impl

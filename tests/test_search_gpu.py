@@ -246,7 +246,7 @@ def test_query_stationary_parity(N, dtype, B, n, d):
     check(s, r, es, er)
     qd, _ = to_dev(N, q, dtype)
     cd, _ = to_dev(N, c, dtype)
-    for dbg in (N.DBG_NO_QS, N.DBG_NO_PREPASS, N.DBG_QS_4_WAVES, N.DBG_QS_4_WAVES | N.DBG_NO_PREPASS):
+    for dbg in (N.DBG_NO_QS, N.DBG_NO_PREPASS, N.DBG_NO_QS | N.DBG_NO_PREPASS):
         s2, r2 = N.cosine_topk(qd, cd, n, d, 5, dbg=dbg)
         assert np.array_equal(r2.cpu().numpy(), r) and np.array_equal(s2.cpu().numpy(), s), dbg
 
@@ -261,7 +261,7 @@ def test_query_stationary_exact_integers_and_ties(N):
         s, r, es, er = run(N, q, c, k, torch.float16)
         assert np.array_equal(s, es)
         assert np.array_equal(r, er)
-        s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_QS_4_WAVES)
+        s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_NO_PREPASS)   # no in-kernel seeding
         assert np.array_equal(s, es)
         assert np.array_equal(r, er)
 
@@ -273,11 +273,11 @@ def test_query_stationary_masks_offsets_ragged(N):
     c = unit_rows(n, d, 42)
     g = np.random.default_rng(43)
     alive = g.random(n) < 0.5
-    for dbg in (0, N.DBG_QS_4_WAVES):
+    for dbg in (0, N.DBG_NO_PREPASS):
         check(*run(N, q, c, 5, torch.float16, row_offset=1_000_000, alive=alive, dbg=dbg))
     few = np.zeros(n, dtype=bool)
     few[[5, 40_000, n - 1]] = True            # 3 live rows < k
     none = np.zeros(n, dtype=bool)
-    for dbg in (0, N.DBG_QS_4_WAVES):
+    for dbg in (0, N.DBG_NO_PREPASS):
         check(*run(N, q, c, 5, torch.float16, alive=few, dbg=dbg))
         check(*run(N, q, c, 5, torch.float16, alive=none, dbg=dbg))

@@ -9,9 +9,9 @@ cands = os.environ.get("CANDS", "default,noqs,nopre").split(",")
 ld = N.padded_dim(d, dtype)
 c = torch.randn((n, ld), device="cuda"); c = (c / c.norm(dim=1, keepdim=True)).to(dtype)
 q = torch.randn((B, ld), device="cuda"); q = (q / q.norm(dim=1, keepdim=True)).to(dtype)
-ws = torch.empty(2 * N.cosine_topk_workspace_bytes(B, n, k) + 4096, dtype=torch.uint8, device="cuda")
+ws = torch.empty(2 * N.cosine_topk_workspace_bytes(B, n, k) + 65536, dtype=torch.uint8, device="cuda")
 def flags(c_):
-    return (8 if "qs4" in c_ else 0) | (16 if "nosel" in c_ else 0) | (32 if "nodma" in c_ else 0) | (64 if "nobar" in c_ else 0) | (128 if "nomfma" in c_ else 0) | (256 if "clk" in c_ else 0) | (0x4000 if "pre1" in c_ else 0) | (0x8000 if "pre2" in c_ else 0) | (0x1000 if "pd2" in c_ else 0) | (0x2000 if "pd5" in c_ else 0) | (0x3000 if "pd7" in c_ else 0) | (512 if "dmal2" in c_ else 0) | (1024 if "nowait" in c_ else 0) | (N.DBG_8_WAVES if "nw8" in c_ else 0) | (N.DBG_NO_PREPASS if "nopre" in c_ else 0) | (N.DBG_NO_QS if "noqs" in c_ else 0)
+    return (8 if "qs4" in c_ else 0) | (16 if "nosel" in c_ else 0) | (32 if "nodma" in c_ else 0) | (64 if "nobar" in c_ else 0) | (128 if "nomfma" in c_ else 0) | (256 if "clk" in c_ else 0) | (128 if "fastonly" in c_ else 0) | (0x4000 if "pre1" in c_ else 0) | (0x8000 if "pre2" in c_ else 0) | (0x1000 if "pd2" in c_ else 0) | (0x2000 if "pd5" in c_ else 0) | (0x3000 if "pd7" in c_ else 0) | (512 if "dmal2" in c_ else 0) | (1024 if "nowait" in c_ else 0) | (N.DBG_8_WAVES if "nw8" in c_ else 0) | (N.DBG_NO_PREPASS if "nopre" in c_ else 0) | (N.DBG_NO_QS if "noqs" in c_ else 0)
 def run(c_, iters=10):
     f = flags(c_)
     N.cosine_topk_lists(q, c, n, d, k, ws, dbg=f)
@@ -36,13 +36,20 @@ need = N.cosine_topk_workspace_bytes(B, n, k) - 256
 import numpy as np
 for c_ in cands:
     if "clk" not in c_: continue
+    ws[need:need + 256 * 64].zero_()
     run(c_, iters=3); torch.cuda.synchronize()
-    st = ws[need:need + 256 * 16].view(torch.int64).cpu().numpy().reshape(256, 2).astype(np.float64)
+    st = ws[need:need + 256 * 64].view(torch.int64).cpu().numpy().reshape(256, 8).astype(np.float64)
     mhz = st[:, 0] / st[:, 1] * 100.0
     us = st[:, 1] / 100.0
     print(f"{c_}: clock MHz min/med/max {mhz.min():.0f}/{np.median(mhz):.0f}/{mhz.max():.0f}; main loop us min/med/max "
           f"{us.min():.1f}/{np.median(us):.1f}/{us.max():.1f}; per XCD-label median us "
           + " ".join(f"{np.median(us[i::8]):.0f}" for i in range(8)))
+    print(f"   entry -> main loop: median {np.median(st[:,2])/100:.1f} us (max {st[:,2].max()/100:.1f}); "
+          f"first entry -> last loop end: {(st[:,3] + st[:,2] + st[:,1]).max()/100 - st[:,3].min()/100:.1f} us; "
+          f"entry skew {(st[:,3].max() - st[:,3].min())/100:.1f} us")
+    if st[:, 5].max() > 0:
+        print(f"   sample phase done at {np.median(st[:,4])/100:.1f} us (min {st[:,4].min()/100:.1f} max {st[:,4].max()/100:.1f}); "
+              f"rendezvous took {np.median(st[:,5]-st[:,4])/100:.1f} us (max {(st[:,5]-st[:,4]).max()/100:.1f})")
 
 # steady state: the chip throttles under sustained MFMA + HBM load (a kernel can run 350 us for the first five
 # launches and 500 us afterwards), so each candidate is also held for STEADY seconds and timed over the second half
