@@ -325,7 +325,7 @@ def main():
 
     if not args.no_embed:
         try:
-            from multimodal_rag_amd import bench_embed
+            import bench_embed
 
             emb = bench_embed.run(dev, rank, world, steps=max(3, args.steps // 5), warmup=2,
                                   with_cpu_baseline=not args.no_cpu_baseline)

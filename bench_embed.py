@@ -1,4 +1,5 @@
 """Embed leg of bench.py: chunks embedded / s (encoder forward + append into the corpus shard).
+Lives next to bench.py (it times the oracle as the CPU baseline, so it is not part of the package).
 
 Workload: bge-base-en-v1.5 architecture (BASELINE.json configs[2]; L=12, H=768, 12 heads,
 I=3072, CLS pooling), random-init fp16 weights, synthetic token ids ([CLS] body [SEP]),
@@ -12,8 +13,8 @@ import time
 import numpy as np
 import torch
 
-from . import _native
-from .encoder import PRESETS, DeviceEncoder, random_bert_weights
+from multimodal_rag_amd import _native
+from multimodal_rag_amd.encoder import PRESETS, DeviceEncoder, random_bert_weights
 
 CHUNKS_PER_STEP = 256
 SEQ = 256
@@ -49,6 +50,10 @@ def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_b
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    t_warm = time.perf_counter() + 0.5   # clocks settle over ~100 ms of load: warm up by time, not by step count
+    while time.perf_counter() < t_warm:
+        step(0)
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
@@ -104,6 +109,10 @@ def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_b
             res["cpu_baseline"]["torch_cpu_error"] = str(e)[:200]
         res["parity_vs_oracle"] = bool(np.abs(got - ref).max() <= 4e-3 and (got * ref).sum(1).min() >= 0.9999)
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+    try:   # "bge 512 and 256", MiniLM (configs 1-2) 256, and ragged lengths
+        res["other_shapes"] = bench_other_shapes(dev)
+    except Exception as e:
+        res["other_shapes"] = {"error": str(e)[:200]}
     try:
         res["clip_vit_b32"] = bench_clip_images(dev)
     except Exception as e:  # the headline numbers must survive a failure of the extra leg
@@ -112,6 +121,62 @@ def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_b
         res["from_text"] = bench_from_text(enc, shard)
     except Exception as e:
         res["from_text"] = {"error": str(e)}
+    return res
+
+
+def _time_forward(enc, ids, pos, cu, max_len, out, seconds=0.4):
+    for _ in range(2):
+        enc.forward_packed(ids, pos, cu, max_len, out=out)
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + seconds / 2
+    while time.perf_counter() < t_end:
+        enc.forward_packed(ids, pos, cu, max_len, out=out)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 0
+    e0.record()
+    t_end = time.perf_counter() + seconds / 2
+    while time.perf_counter() < t_end:
+        enc.forward_packed(ids, pos, cu, max_len, out=out)
+        n += 1
+        if n % 4 == 0:
+            torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def bench_other_shapes(dev):
+    """Forward-only chunks/s at the other shapes SURVEY 8d names: bge-base S=512, all-MiniLM-L6-v2 S=256, and
+    bge-base with clipped log-normal lengths (mean ~180, max 256; no padded tokens are computed)."""
+    res = {}
+    for name, key, S, chunks in (("bge_base_s512", "BAAI/bge-base-en-v1.5", 512, 128),
+                                 ("minilm_l6_s256", "sentence-transformers/all-MiniLM-L6-v2", 256, 256)):
+        cfg = PRESETS[key]
+        enc = DeviceEncoder(cfg, random_bert_weights(cfg, seed=77, device=dev), dev)
+        ids = torch.from_numpy(synthetic_ids(chunks, S, cfg.vocab, seed=9).reshape(-1)).to(dev)
+        pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(chunks)
+        cu = torch.arange(0, (chunks + 1) * S, S, dtype=torch.int32, device=dev)
+        out = torch.empty((chunks, cfg.dim), dtype=torch.float32, device=dev)
+        ms = _time_forward(enc, ids, pos, cu, S, out)
+        tf = chunks * enc.flops_per_sequence(S) / (ms * 1e-3) / 1e12
+        res[name] = {"chunks_per_s": round(chunks / ms * 1e3, 1), "ms_per_step": round(ms, 3), "chunks_per_step": chunks,
+                     "seq_len": S, "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4)}
+        del enc
+    cfg = PRESETS["BAAI/bge-base-en-v1.5"]
+    enc = DeviceEncoder(cfg, random_bert_weights(cfg, seed=78, device=dev), dev)
+    g = np.random.default_rng(12)
+    lens = np.clip(np.exp(g.normal(np.log(170.0), 0.45, size=256)).astype(np.int64), 8, 256)
+    T = int(lens.sum())
+    ids = torch.from_numpy(g.integers(1000, cfg.vocab, size=T).astype(np.int32)).to(dev)
+    pos = torch.from_numpy(np.concatenate([np.arange(n, dtype=np.int32) for n in lens])).to(dev)
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    out = torch.empty((256, cfg.dim), dtype=torch.float32, device=dev)
+    ms = _time_forward(enc, ids, pos, cu, int(lens.max()), out)
+    useful = float(sum(enc.flops_per_sequence(int(n)) for n in lens))
+    res["bge_base_lognormal"] = {"chunks_per_s": round(256 / ms * 1e3, 1), "ms_per_step": round(ms, 3),
+                                 "mean_tokens_per_chunk": round(T / 256, 1), "max_tokens": int(lens.max()),
+                                 "useful_tflops": round(useful / (ms * 1e-3) / 1e12, 1)}
     return res
 
 
@@ -182,7 +247,7 @@ def bench_from_text(enc: DeviceEncoder, shard: torch.Tensor, n_chunks: int = 102
     while the GPU encodes the previous one, H2D of the packed ids, encoder forward, append to the shard."""
     import threading
 
-    from .tokenizer import NativeWordPieceTokenizer
+    from multimodal_rag_amd.tokenizer import NativeWordPieceTokenizer
 
     vocab, words = synthetic_vocab(enc.cfg.vocab)
     tk = NativeWordPieceTokenizer(vocab)
@@ -233,7 +298,7 @@ def bench_from_text(enc: DeviceEncoder, shard: torch.Tensor, n_chunks: int = 102
 
 def bench_clip_images(dev, n_images: int = 256, steps: int = 5):
     """Extra (BASELINE config 4): CLIP ViT-B/32 vision tower, uint8 224x224 tiles -> 512-d, images/s."""
-    from .clip import VIT_B32, DeviceClip
+    from multimodal_rag_amd.clip import VIT_B32, DeviceClip
 
     clip = DeviceClip.random_init(VIT_B32, seed=7, device=dev)
     g = torch.Generator(device=dev).manual_seed(3)

@@ -61,6 +61,12 @@ def _declare(lib):
     lib.mmrag_gather_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]
     lib.mmrag_fetch_rows_f32.restype = c_int
     lib.mmrag_fetch_rows_f32.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]
+    lib.mmrag_device_info.restype = c_int
+    lib.mmrag_device_info.argtypes = [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]
+    lib.mmrag_bench_stream_copy.restype = c_int
+    lib.mmrag_bench_stream_copy.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    lib.mmrag_bench_mfma_f16.restype = c_int
+    lib.mmrag_bench_mfma_f16.argtypes = [c_void_p, c_void_p, c_int, ctypes.POINTER(c_int64), c_void_p]
     lib.mmrag_copy_to_host_async.restype = c_int
     lib.mmrag_copy_to_host_async.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mmrag_encoder_workspace_bytes.restype = c_size_t
@@ -174,6 +180,57 @@ def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, r
                                  workspace.numel() * workspace.element_size(), _stream_ptr(q.device))
     _check(st, "mmrag_cosine_topk")
     return out_s, out_r
+
+
+def device_info() -> dict:
+    """CU count, maximum shader clock and HBM size of the current device (mmrag_device_info)"""
+    cus, mhz, mem = c_int(0), c_int(0), c_int64(0)
+    _check(lib().mmrag_device_info(ctypes.byref(cus), ctypes.byref(mhz), ctypes.byref(mem)), "mmrag_device_info")
+    return {"compute_units": cus.value, "max_clock_mhz": mhz.value, "hbm_bytes": mem.value}
+
+
+def measure_peaks(device: torch.device, seconds: float = 0.4) -> dict:
+    """Measured stream-copy bandwidth and fp16 MFMA rate of this device (the library's own micro-kernels,
+    each held for `seconds` so the chip reaches the clock it sustains): the second set of roofline peaks."""
+    L = lib()
+    out = {}
+    with torch.cuda.device(device):
+        stream = _stream_ptr(device)
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        src.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def timed(fn, min_s):
+            import time
+            fn(); torch.cuda.synchronize(device)
+            t_end = time.time() + min_s / 2
+            while time.time() < t_end:   # reach the sustained clock first
+                for _ in range(4): fn()
+                torch.cuda.synchronize(device)
+            n = 0
+            e0.record()
+            t_end = time.time() + min_s / 2
+            while time.time() < t_end:
+                for _ in range(4): fn()
+                n += 4
+                torch.cuda.synchronize(device)
+            e1.record(); torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) * 1e-3 / n
+
+        t = timed(lambda: _check(L.mmrag_bench_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, stream), "copy"), seconds)
+        out["stream_copy_GBps"] = round(2 * nbytes / t / 1e9, 1)      # bytes read + bytes written
+        out["stream_copy_read_GBps"] = round(nbytes / t / 1e9, 1)
+        del src, dst
+        seed = (torch.randn(256 * 8, device=device) * 0.5).to(torch.float16)
+        res = torch.empty(256 * 1024, dtype=torch.float32, device=device)
+        flops = c_int64(0)
+        iters = 20000
+        t = timed(lambda: _check(L.mmrag_bench_mfma_f16(seed.data_ptr(), res.data_ptr(), iters, ctypes.byref(flops), stream),
+                                 "mfma"), seconds)
+        out["mfma_f16_TFLOPs"] = round(flops.value / t / 1e12, 1)
+    return out
 
 
 def cosine_topk_workspace_bytes(B: int, n: int, k: int) -> int:

@@ -9,6 +9,7 @@ Weights use Hugging Face `CLIPModel` state_dict names (local checkpoint or rando
 from __future__ import annotations
 
 import ctypes
+import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -156,6 +157,7 @@ class DeviceClip:
             image=cfg.image, patch=cfg.patch)
         self._ws_t: Optional[torch.Tensor] = None
         self._ws_v: Optional[torch.Tensor] = None
+        self._launch_lock = threading.Lock()
 
     @classmethod
     def random_init(cls, cfg: ClipConfig = VIT_B32, seed: int = 0, device="cuda:0") -> "DeviceClip":
@@ -202,10 +204,11 @@ class DeviceClip:
         ids = torch.from_numpy(np.concatenate(seqs)).to(d)
         pos = torch.from_numpy(np.concatenate([np.arange(n, dtype=np.int32) for n in lens])).to(d)
         need = _native.encoder_workspace_bytes(self.text_desc, int(cu[-1]), len(seqs))
-        if self._ws_t is None or self._ws_t.numel() < need:
-            self._ws_t = torch.empty(need, dtype=torch.uint8, device=d)
-        return _native.encoder_forward(self.text_desc, self._text_tab, ids, pos, torch.from_numpy(cu).to(d),
-                                       int(lens.max()), sel=torch.from_numpy(eos).to(d), workspace=self._ws_t)
+        with self._launch_lock:   # one workspace per tower: launches of two forwards must not interleave
+            if self._ws_t is None or self._ws_t.numel() < need:
+                self._ws_t = torch.empty(need, dtype=torch.uint8, device=d)
+            return _native.encoder_forward(self.text_desc, self._text_tab, ids, pos, torch.from_numpy(cu).to(d),
+                                           int(lens.max()), sel=torch.from_numpy(eos).to(d), workspace=self._ws_t)
 
     def encode_images(self, pixels: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """uint8 [B, image, image, 3] raw crops (normalised on the GPU) or fp16 [B, 3, image, image]
@@ -222,9 +225,10 @@ class DeviceClip:
         B, S = pixels.shape[0], self.cfg.tokens_per_image
         cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=self.device)
         need = _native.encoder_workspace_bytes(self.vis_desc, B * S, B)
-        if self._ws_v is None or self._ws_v.numel() < need:
-            self._ws_v = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return _native.vit_forward(self.vis_desc, self._vis_tab, pixels, kind, cu, workspace=self._ws_v, out=out)
+        with self._launch_lock:
+            if self._ws_v is None or self._ws_v.numel() < need:
+                self._ws_v = torch.empty(need, dtype=torch.uint8, device=self.device)
+            return _native.vit_forward(self.vis_desc, self._vis_tab, pixels, kind, cu, workspace=self._ws_v, out=out)
 
     def image_flops(self) -> float:
         c = self.cfg

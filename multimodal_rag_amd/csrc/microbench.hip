@@ -1,0 +1,75 @@
+// Measured peaks for the roofline report ("measure a stream-copy bandwidth and an
+// MFMA micro-benchmark peak on the box; fractions against both vendor and measured").  Two tiny kernels and a device
+// query, exported through the C-ABI so bench.py measures them in the same run as the hot path.
+#include "mmrag_internal.h"
+#include "tile_dma.h"
+
+using namespace mmrag;
+
+namespace mmrag_impl {
+
+// 16 bytes per lane, grid-stride: the copy the 6.3 TB/s figure of MI355X_MICROARCH.md is quoted on
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(u32x4_t *__restrict__ dst, const u32x4_t *__restrict__ src,
+                                                          long long n_vec) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// Back-to-back v_mfma_f32_32x32x16_f16 on four independent accumulators per wave, operands from `seed` (random data:
+// the clock the chip holds under an MFMA load depends on the operand values, so zeros would flatter the peak).
+// One wave per SIMD at 256 threads per workgroup and one workgroup per CU.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(const half8_t *__restrict__ seed, float *__restrict__ out,
+                                                        int iters) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63;
+    const half8_t a0 = seed[lane], a1 = seed[64 + lane], b0 = seed[128 + lane], b1 = seed[192 + lane];
+    f32x16_t c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, c3, 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += c0[j] + c1[j] + c2[j] + c3[j];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+#endif
+}
+
+}  // namespace mmrag_impl
+using namespace mmrag_impl;
+
+extern "C" {
+
+int mmrag_device_info(int *n_cus, int *max_clock_mhz, int64_t *hbm_bytes) {
+    int dev = 0;
+    MMRAG_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    MMRAG_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (n_cus) *n_cus = prop.multiProcessorCount;
+    if (max_clock_mhz) *max_clock_mhz = prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return MMRAG_OK;
+}
+
+int mmrag_bench_stream_copy(void *dst, const void *src, int64_t bytes, void *stream) {
+    MMRAG_CHECK_ARG(dst && src && bytes > 0 && bytes % 16 == 0, "bench_stream_copy: need 16-byte multiples");
+    MMRAG_CHECK_ARG(((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0, "bench_stream_copy: 16-byte alignment");
+    stream_copy_kernel<<<num_cus() * 8, 256, 0, (hipStream_t)stream>>>((u32x4_t *)dst, (const u32x4_t *)src, bytes / 16);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_bench_mfma_f16(const void *seed, float *out, int iters, int64_t *flops, void *stream) {
+    MMRAG_CHECK_ARG(seed && out && iters > 0, "bench_mfma_f16: bad arguments");
+    const int grid = num_cus();
+    mfma_peak_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half8_t *)seed, out, iters);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    if (flops) *flops = (int64_t)grid * 4 /*waves*/ * (int64_t)iters * 4 /*MFMAs*/ * (2LL * 32 * 32 * 16);
+    return MMRAG_OK;
+}
+
+}  // extern "C"

@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes
 import json
 import os
+import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -132,6 +133,10 @@ class DeviceEncoder:
             pool=_native.POOL_MEAN if cfg.pool == "mean" else _native.POOL_FIRST, act=_native.ACT_GELU, causal=0,
             normalize=1, out_dim=cfg.hidden, ln_eps=cfg.ln_eps)
         self._workspace: Optional[torch.Tensor] = None
+        # One workspace, one stream: the launches of two forwards must not interleave (the service encodes from
+        # asyncio.to_thread workers, embedder.py:368, and ctypes drops the GIL).  Held while the kernels are
+        # ENQUEUED; stream order then keeps the forwards apart on the device.
+        self._launch_lock = threading.Lock()
 
     # ---------------------------------------------------------------- constructors ---------
     @classmethod
@@ -210,10 +215,11 @@ class DeviceEncoder:
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         T, B = ids.numel(), cu_seqlens.numel() - 1
         need = _native.encoder_workspace_bytes(self.desc, T, B)
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return _native.encoder_forward(self.desc, self._ptrs, ids, pos_ids, cu_seqlens, max_len,
-                                       workspace=self._workspace, out=out)
+        with self._launch_lock:
+            if self._workspace is None or self._workspace.numel() < need:
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            return _native.encoder_forward(self.desc, self._ptrs, ids, pos_ids, cu_seqlens, max_len,
+                                           workspace=self._workspace, out=out)
 
     @property
     def dim(self) -> int:

@@ -139,7 +139,21 @@ _UNHASHABLE = object()
 
 
 class VectorIndex:
-    """One shard of the corpus matrix on one GPU plus its host-side row tables."""
+    """One shard of the corpus matrix on one GPU plus its host-side row tables.
+
+    Rows are appended in insertion order and never move while they are alive, so "lower row" always means
+    "earlier insert" (the tie rule).  A delete is a TOMBSTONE: the row's bit is cleared in a device-resident alive
+    bitmap that the search kernels consume (masked rows start at -inf, csrc/search*.hip), its id leaves the id map,
+    and nothing else is touched -- `delete_document` on a 1M-row shard is O(victims) on the host and one small
+    scatter on the device.  The matrix is compacted (stably) only when more than COMPACT_DEAD_FRACTION of the rows
+    are dead, or on `compact()` / save.
+
+    Vectors must be unit-norm (cosine = inner product of unit vectors; `distance = 1 - cos`).  The encoders of this
+    package normalise; `add` / `query` reject rows whose norm is off by more than 1e-2 instead of silently ranking
+    by raw inner product (Chroma's cosine space would have normalised them)."""
+
+    COMPACT_DEAD_FRACTION = 0.25
+    COMPACT_MIN_DEAD = 4096
 
     def __init__(self, dim: int, dtype: torch.dtype = torch.float16, device: str = "cuda:0",
                  capacity: int = 4096, name: str = "multimodal_rag",
@@ -153,14 +167,22 @@ class VectorIndex:
         self.dtype = dtype
         self.device = torch.device(device)
         self.ld = _native.padded_dim(self.dim, dtype)
-        self._matrix = torch.zeros((max(int(capacity), 256), self.ld), dtype=dtype, device=self.device)
-        self._n = 0
-        self._ids: List[str] = []
+        cap = max(int(capacity), 256)
+        self._matrix = torch.zeros((cap, self.ld), dtype=dtype, device=self.device)
+        self._alive_dev = torch.zeros(self._n_words(cap), dtype=torch.int32, device=self.device)
+        self._alive_host = np.zeros(self._n_words(cap), dtype=np.uint32)
+        self._n = 0            # rows in use (alive + dead)
+        self._n_dead = 0
+        self._ids: List[Optional[str]] = []
         self._documents: List[Optional[str]] = []
         self._metadatas: List[Dict[str, Any]] = []
         self._meta_index = MetaIndex()
         self._row_of: Dict[str, int] = {}
         self._lock = threading.RLock()
+
+    @staticmethod
+    def _n_words(rows: int) -> int:
+        return (rows + 31) // 32 + 8   # the kernels read whole words of the last tile
 
     # ------------------------------------------------------------------ storage ----------
     @property
@@ -168,6 +190,11 @@ class VectorIndex:
         return self._matrix
 
     def count(self) -> int:
+        return self._n - self._n_dead
+
+    @property
+    def rows_in_use(self) -> int:
+        """rows of the matrix that hold a vector, dead ones included (what the kernels scan)"""
         return self._n
 
     def _reserve(self, rows: int):
@@ -175,9 +202,39 @@ class VectorIndex:
         if rows <= cap:
             return
         new_cap = max(rows, cap * 2)
-        grown = torch.zeros((new_cap, self.ld), dtype=self.dtype, device=self.device)
+        grown = torch.empty((new_cap, self.ld), dtype=self.dtype, device=self.device)
         grown[: self._n].copy_(self._matrix[: self._n])
+        grown[self._n:].zero_()
         self._matrix = grown
+        words = torch.zeros(self._n_words(new_cap), dtype=torch.int32, device=self.device)
+        words[: self._alive_dev.numel()].copy_(self._alive_dev)
+        self._alive_dev = words
+        host = np.zeros(self._n_words(new_cap), dtype=np.uint32)
+        host[: self._alive_host.size] = self._alive_host
+        self._alive_host = host
+
+    def _set_alive(self, lo: int, hi: int):
+        """mark rows [lo, hi) alive (appends): touch only the words they fall in"""
+        idx = np.arange(lo, hi, dtype=np.int64)
+        np.bitwise_or.at(self._alive_host, idx >> 5, np.uint32(1) << (idx & 31).astype(np.uint32))
+        w0, w1 = lo >> 5, ((hi - 1) >> 5) + 1
+        self._alive_dev[w0:w1].copy_(torch.from_numpy(self._alive_host[w0:w1].view(np.int32)), non_blocking=False)
+
+    def _clear_alive(self, rows: np.ndarray):
+        np.bitwise_and.at(self._alive_host, rows >> 5, ~(np.uint32(1) << (rows & 31).astype(np.uint32)))
+        touched = np.unique(rows >> 5)
+        self._alive_dev[torch.from_numpy(touched).to(self.device)] = torch.from_numpy(
+            self._alive_host[touched].view(np.int32)).to(self.device)
+
+    def _check_unit_norm(self, t: torch.Tensor, what: str):
+        if t.shape[0] == 0:
+            return
+        nrm = torch.linalg.vector_norm(t, dim=1)
+        bad = (nrm - 1.0).abs() > 1e-2
+        if bool(bad.any()):
+            i = int(torch.nonzero(bad)[0])
+            raise ValueError(f"{what}: row {i} has norm {float(nrm[i]):.4f}; this collection is cosine "
+                             f"(inner product of unit vectors) -- L2-normalise the vectors first")
 
     def _to_device_f32(self, x) -> torch.Tensor:
         if isinstance(x, torch.Tensor):
@@ -193,6 +250,7 @@ class VectorIndex:
     def _pack_queries(self, q) -> torch.Tensor:
         """float32 [B, d] -> storage dtype [B, ld] with zero pad columns (device-side cast kernel)."""
         qf = self._to_device_f32(q)
+        self._check_unit_norm(qf, "query")
         packed = torch.empty((qf.shape[0], self.ld), dtype=self.dtype, device=self.device)
         _native.append_rows(packed, 0, qf, self.dim)
         return packed
@@ -203,6 +261,7 @@ class VectorIndex:
         if ids is None:
             raise ValueError("ids are required")
         emb = self._to_device_f32(embeddings)
+        self._check_unit_norm(emb, "add")
         m = emb.shape[0]
         if len(ids) != m:
             raise ValueError(f"{len(ids)} ids for {m} embeddings")
@@ -231,6 +290,7 @@ class VectorIndex:
                 self._documents.append(documents[i])
                 self._metadatas.append(metadatas[i])
             self._meta_index.append([metadatas[i] for i in keep])
+            self._set_alive(self._n, self._n + len(keep))
             self._n += len(keep)
 
     def add_rows_device(self, rows_packed: torch.Tensor, documents, metadatas, ids):
@@ -245,92 +305,109 @@ class VectorIndex:
             self._documents.extend(documents if documents is not None else [None] * m)
             self._metadatas.extend(metadatas if metadatas is not None else [{} for _ in range(m)])
             self._meta_index.append(self._metadatas[self._n: self._n + m])
+            self._set_alive(self._n, self._n + m)
             self._n += m
 
+    def _is_dead(self, rows: np.ndarray) -> np.ndarray:
+        return ((self._alive_host[rows >> 5] >> (rows & 31).astype(np.uint32)) & 1) == 0
+
     def _rows_where(self, where: Optional[Dict[str, Any]]) -> np.ndarray:
-        """Ascending rows whose metadata matches `where` (inverted index when the form allows, else a scan)."""
+        """Ascending LIVE rows whose metadata matches `where` (inverted index when the form allows, else a scan)."""
         fast = self._meta_index.rows(where)
-        if fast is not None:
-            return fast
-        return np.fromiter((i for i in range(self._n) if match_where(self._metadatas[i], where)), dtype=np.int64)
+        if fast is None:
+            fast = np.fromiter((i for i in range(self._n)
+                                if self._ids[i] is not None and match_where(self._metadatas[i], where)), dtype=np.int64)
+        if self._n_dead and fast.size:
+            fast = fast[~self._is_dead(fast)]
+        return fast
 
-    def _alive_words(self, where: Optional[Dict[str, Any]]) -> Optional[np.ndarray]:
+    def _where_bits(self, where: Optional[Dict[str, Any]]) -> Optional[torch.Tensor]:
+        """device alive bitmap for one search: tombstones AND `where` (ANDed on the device), or None = every row"""
         if not where:
-            return None
-        n_words = (self._n + 31) // 32 + 8
-        flags = np.zeros(n_words * 32, dtype=bool)
+            return self._alive_dev if self._n_dead else None
+        flags = np.zeros(self._alive_host.size * 32, dtype=bool)
         flags[self._rows_where(where)] = True
-        return np.packbits(flags, bitorder="little").view(np.uint32)   # bit r%32 of word r//32 = row r alive
+        words = torch.from_numpy(np.packbits(flags, bitorder="little").view(np.int32)).to(self.device)
+        return torch.bitwise_and(words, self._alive_dev) if self._n_dead else words
 
-    def _to_bits(self, words: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(words.view(np.int32)).to(self.device)
+    def _launch_search(self, query_embeddings, n_results: int, where):
+        """enqueue the search (caller holds the lock); returns device tensors, no host sync"""
+        if n_results < 1:
+            raise ValueError("n_results must be >= 1")
+        q = self._pack_queries(query_embeddings)
+        bits = self._where_bits(where)
+        if n_results <= _native.MAX_K:
+            return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
+        if q.shape[0] != 1:
+            raise ValueError(f"n_results > {_native.MAX_K} is supported for single queries only")
+        # deeper than the kernel's lists (get_similar_documents asks for n_results + 1): further passes with the rows
+        # already returned masked out -- still exact, still ordered
+        if bits is None:
+            bits = self._alive_dev
+        bits = bits.clone()
+        out_s, out_r, left = [], [], n_results
+        while left > 0:
+            k = min(left, _native.MAX_K)
+            s, r = _native.cosine_topk(q, self._matrix, self._n, self.dim, k, alive_bits=bits)
+            out_s.append(s)
+            out_r.append(r)
+            got = r[0]
+            got = got[got >= 0]
+            if got.numel() < k:
+                break
+            host = got.cpu().numpy()
+            w = bits.cpu().numpy().view(np.uint32).copy()
+            np.bitwise_and.at(w, host >> 5, ~(np.uint32(1) << (host & 31).astype(np.uint32)))
+            bits = torch.from_numpy(w.view(np.int32)).to(self.device)
+            left -= k
+        return torch.cat(out_s, 1), torch.cat(out_r, 1)
 
     def search(self, query_embeddings, n_results: int, where: Optional[Dict[str, Any]] = None):
         """Raw device search: (scores [B, k] float32 desc, rows [B, k] int64, -1 = none).
 
-        The kernel selects up to MAX_K = 20 per pass (api.py:163 caps top_k at 20).  Deeper
-        requests (get_similar_documents asks for n_results + 1, embedder.py:903) run further
-        passes with the rows already returned masked out -- still exact, still ordered."""
-        if n_results < 1:
-            raise ValueError("n_results must be >= 1")
+        The kernel selects up to MAX_K = 20 per pass (api.py:163 caps top_k at 20)."""
         with self._lock:
-            q = self._pack_queries(query_embeddings)
-            words = self._alive_words(where)
-            if n_results <= _native.MAX_K:
-                bits = self._to_bits(words) if words is not None else None
-                return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
-            if q.shape[0] != 1:
-                raise ValueError(f"n_results > {_native.MAX_K} is supported for single queries only")
-            if words is None:
-                words = np.zeros((self._n + 31) // 32 + 8, dtype=np.uint32)
-                idx = np.arange(self._n, dtype=np.int64)
-                np.bitwise_or.at(words, idx // 32, np.uint32(1) << (idx % 32).astype(np.uint32))
-            out_s, out_r, left = [], [], n_results
-            while left > 0:
-                k = min(left, _native.MAX_K)
-                s, r = _native.cosine_topk(q, self._matrix, self._n, self.dim, k, alive_bits=self._to_bits(words))
-                out_s.append(s)
-                out_r.append(r)
-                got = r[0].cpu().numpy()
-                got = got[got >= 0]
-                if got.size < k:
-                    break
-                np.bitwise_and.at(words, got // 32, ~(np.uint32(1) << (got % 32).astype(np.uint32)))
-                left -= k
-            return torch.cat(out_s, 1), torch.cat(out_r, 1)
+            return self._launch_search(query_embeddings, n_results, where)
 
     def query(self, query_embeddings, n_results: int = 10, where: Optional[Dict[str, Any]] = None,
               include: Sequence[str] = ("metadatas", "documents", "distances")) -> Dict[str, Any]:
-        """Chroma-shaped result: lists of lists, ascending distance = 1 - cos, at most count() hits."""
+        """Chroma-shaped result: lists of lists, ascending distance = 1 - cos, at most count() hits.
+
+        The lock is held only while the kernels are enqueued: concurrent callers (asyncio.to_thread workers,
+        embedder.py:595) overlap their host waits and result building.  Row tables are append-only between
+        compactions and a compaction swaps in NEW lists, so the snapshot taken under the lock stays valid."""
         with self._lock:
-            scores, rows = self.search(query_embeddings, n_results, where)
-            scores = scores.cpu().numpy()
-            rows = rows.cpu().numpy()
-            out: Dict[str, Any] = {"ids": []}
-            for key in ("distances", "metadatas", "documents", "embeddings"):
-                out[key] = [] if key in include else None
-            for b in range(rows.shape[0]):
-                hit = [int(r) for r in rows[b] if r >= 0]
-                out["ids"].append([self._ids[r] for r in hit])
-                if "distances" in include:
-                    out["distances"].append([float(np.float32(1.0) - scores[b, j]) for j in range(len(hit))])
-                if "metadatas" in include:
-                    out["metadatas"].append([dict(self._metadatas[r]) for r in hit])
-                if "documents" in include:
-                    out["documents"].append([self._documents[r] for r in hit])
-                if "embeddings" in include:
-                    out["embeddings"].append(self._fetch(hit))
-            return out
+            scores, rows = self._launch_search(query_embeddings, n_results, where)
+            ids_t, docs_t, metas_t = self._ids, self._documents, self._metadatas
+            emb_src = self._matrix if "embeddings" in include else None
+        scores = scores.cpu().numpy()
+        rows = rows.cpu().numpy()
+        out: Dict[str, Any] = {"ids": []}
+        for key in ("distances", "metadatas", "documents", "embeddings"):
+            out[key] = [] if key in include else None
+        for b in range(rows.shape[0]):
+            hit = [int(r) for r in rows[b] if r >= 0]
+            out["ids"].append([ids_t[r] for r in hit])
+            if "distances" in include:
+                out["distances"].append([float(np.float32(1.0) - scores[b, j]) for j in range(len(hit))])
+            if "metadatas" in include:
+                out["metadatas"].append([dict(metas_t[r]) for r in hit])
+            if "documents" in include:
+                out["documents"].append([docs_t[r] for r in hit])
+            if "embeddings" in include:
+                out["embeddings"].append(self._fetch(hit, emb_src))
+        return out
 
     def ids_of_rows(self, rows: Sequence[int]) -> List[str]:
-        """ids of the given local rows (row numbers are only stable until the next delete)."""
+        """ids of the given local rows (row numbers are stable until the next compaction)."""
         with self._lock:
             return [self._ids[int(r)] for r in rows]
 
-    def _fetch(self, rows: List[int]) -> List[List[float]]:
+    def _fetch(self, rows: List[int], matrix: Optional[torch.Tensor] = None) -> List[List[float]]:
         if not rows:
             return []
-        t = _native.fetch_rows_f32(self._matrix, torch.tensor(rows, dtype=torch.int64, device=self.device), self.dim)
+        m = self._matrix if matrix is None else matrix
+        t = _native.fetch_rows_f32(m, torch.tensor(rows, dtype=torch.int64, device=self.device), self.dim)
         return t.cpu().numpy().tolist()
 
     def get(self, ids: Optional[Sequence[str]] = None, where: Optional[Dict[str, Any]] = None,
@@ -348,30 +425,59 @@ class VectorIndex:
             return out
 
     def delete(self, ids: Optional[Sequence[str]] = None, where: Optional[Dict[str, Any]] = None) -> List[str]:
-        """Remove rows and compact the matrix (stable: survivors keep their insertion order, so
-        the lower-row-first tie rule keeps meaning 'earlier insert first')."""
+        """Tombstone the matching rows (collection.delete, embedder.py:639-642): clear their alive bits on the
+        device, drop them from the id map.  O(victims); the matrix is compacted only past COMPACT_DEAD_FRACTION."""
         with self._lock:
-            victims = set(self.get(ids=ids, where=where, include=())["ids"])
-            if not victims:
-                return []
-            keep = [r for r in range(self._n) if self._ids[r] not in victims]
-            if keep:
-                dst = torch.zeros_like(self._matrix)
-                _native.gather_rows(dst, self._matrix, torch.tensor(keep, dtype=torch.int64, device=self.device))
-                self._matrix = dst
+            if ids is not None:
+                rows = [self._row_of[i] for i in ids if i in self._row_of]
+                if where:
+                    rows = [r for r in rows if match_where(self._metadatas[r], where)]
+                rows = np.asarray(sorted(set(rows)), dtype=np.int64)
             else:
-                self._matrix.zero_()
+                rows = self._rows_where(where)
+            if rows.size == 0:
+                return []
+            gone = [self._ids[int(r)] for r in rows]
+            for r, s in zip(rows.tolist(), gone):
+                del self._row_of[s]
+                self._ids[r] = None
+                self._documents[r] = None
+            self._clear_alive(rows)
+            self._n_dead += int(rows.size)
+            if self._n_dead >= self.COMPACT_MIN_DEAD and self._n_dead > self.COMPACT_DEAD_FRACTION * self._n:
+                self.compact()
+            return sorted(gone)
+
+    def compact(self):
+        """Drop the dead rows (stable: survivors keep their order).  New tables and a new matrix are swapped in, so
+        result-building threads that still hold the old ones are unaffected."""
+        with self._lock:
+            if self._n_dead == 0:
+                return
+            keep = np.nonzero(~self._is_dead(np.arange(self._n, dtype=np.int64)))[0]
+            cap = max(256, int(keep.size), self._matrix.shape[0] // 2 if keep.size < self._matrix.shape[0] // 4 else self._matrix.shape[0])
+            dst = torch.zeros((cap, self.ld), dtype=self.dtype, device=self.device)
+            if keep.size:
+                _native.gather_rows(dst, self._matrix, torch.from_numpy(keep).to(self.device))
+            self._matrix = dst
             self._ids = [self._ids[r] for r in keep]
             self._documents = [self._documents[r] for r in keep]
             self._metadatas = [self._metadatas[r] for r in keep]
             self._row_of = {s: i for i, s in enumerate(self._ids)}
-            self._n = len(keep)
+            self._n = int(keep.size)
+            self._n_dead = 0
             self._meta_index = MetaIndex()
             self._meta_index.append(self._metadatas)
-            return sorted(victims)
+            self._alive_host = np.zeros(self._n_words(cap), dtype=np.uint32)
+            self._alive_dev = torch.zeros(self._n_words(cap), dtype=torch.int32, device=self.device)
+            if self._n:
+                self._set_alive(0, self._n)
 
     def reset(self):
         with self._lock:
             self._n = 0
+            self._n_dead = 0
             self._ids, self._documents, self._metadatas, self._row_of = [], [], [], {}
             self._meta_index = MetaIndex()
+            self._alive_host[:] = 0
+            self._alive_dev.zero_()

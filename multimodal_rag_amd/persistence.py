@@ -97,6 +97,7 @@ def save_index(index, directory: str) -> None:
     import torch
 
     os.makedirs(directory, exist_ok=True)
+    index.compact()   # tombstoned rows are not persisted
     n = index.count()
     m = index.matrix[:n].cpu()
     raw = m.view(torch.int16).numpy() if m.dtype in (torch.float16, torch.bfloat16) else m.numpy()

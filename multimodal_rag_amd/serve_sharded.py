@@ -24,10 +24,12 @@ from .serving import ShardedCollection
 class ShardedEngine:
     """An encoder engine whose collections are sharded over the process group (rank 0 side)."""
 
-    def __init__(self, engine, device: torch.device, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, engine, device: torch.device, group: Optional[dist.ProcessGroup] = None,
+                 control_group: Optional[dist.ProcessGroup] = None):
         self._engine = engine
         self._device = device
         self._group = group
+        self._control = control_group
         self._col: Optional[ShardedCollection] = None
 
     def __getattr__(self, name):            # encode / encode_images / dim / max_seq_length / release ...
@@ -36,7 +38,7 @@ class ShardedEngine:
     def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):
         if self._col is None:
             self._col = ShardedCollection(self._engine.new_collection(name, metadata), self._group, self._device,
-                                          encode_fn=self._engine.encode)
+                                          encode_fn=self._engine.encode, control_group=self._control)
         else:                                # delete_all_documents re-creates the collection (embedder.py:670-678)
             self._col.reset()
         return self._col
@@ -60,6 +62,12 @@ def main(argv=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29544")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # the control plane (command headers, ingest batches, winners' payload) runs on gloo with a timeout no idle
+    # period can reach: workers block in it between requests, and the RCCL group's watchdog (10 minutes by default)
+    # would abort them.  RCCL carries the per-query all-gather only.
+    import datetime
+
+    control = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=365))
     try:
         if rank == 0:
             import uvicorn
@@ -72,7 +80,7 @@ def main(argv=None):
             engine = factory(name, f"cuda:{local}")
             box = [engine.dim]
             dist.broadcast_object_list(box, src=0)
-            sharded = ShardedEngine(engine, dev)
+            sharded = ShardedEngine(engine, dev, control_group=control)
             manager = EmbeddingManager(batch_size=32, enable_cache=True, engine=sharded)
             try:
                 uvicorn.run(create_app(embedder=manager), host=args.host, port=args.port, log_level=settings.LOG_LEVEL.lower())
@@ -89,7 +97,7 @@ def main(argv=None):
             engine = factory(name, f"cuda:{local}")      # every rank holds the encoder: ingest is data-parallel
             assert engine.dim == int(box[0])
             shard = engine.new_collection(settings.CHROMA_COLLECTION_NAME)
-            ShardedCollection(shard, device=dev, encode_fn=engine.encode).worker_loop()
+            ShardedCollection(shard, device=dev, encode_fn=engine.encode, control_group=control).worker_loop()
     finally:
         dist.destroy_process_group()
 

@@ -37,9 +37,32 @@ from . import _native
 logger = logging.getLogger(__name__)
 
 
+class ShardError(RuntimeError):
+    """a rank's local step of a collection command failed; raised on rank 0 with every failing rank's message"""
+
+
+OP_STOP, OP_QUERY, OP_OBJECT = 0, 1, 2
+_INCLUDE_BITS = {"distances": 1, "metadatas": 2, "documents": 4, "embeddings": 8}
+_FAILED_ROW = -2      # first sequence number of a rank's packed block when its local search raised
+
+
 class ShardedCollection:
+    """Control plane and data plane are separate:
+
+    * control (`control_group`, default = `group`): a fixed 8-word int64 header per command, and pickled objects
+      only for what is not a tensor (ingest batches, get / delete arguments, `where` dicts, the winners' payload).
+      Give it a gloo group with a long timeout: workers block in it between requests, and a collective watchdog (the
+      default 10 minutes of an RCCL group) would abort an idle service.
+    * data (`group`, buffers on `device`): a query = header + the [B, d] float32 query matrix as a tensor broadcast,
+      ONE all-gather of the packed per-rank candidates, the C++ host merge.  Nothing is pickled on that path.
+
+    Every command is: local step on every rank (may raise) -> status exchange -> finish on rank 0.  A rank whose
+    local step raised reports it instead of leaving the collective sequence, so rank 0 raises `ShardError` and the
+    service keeps running."""
+
     def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None,
-                 shard_io=None, encode_fn=None):
+                 shard_io=None, encode_fn=None, control_group: Optional[dist.ProcessGroup] = None,
+                 encode_batch: int = 32):
         """`shard`: this rank's VectorIndex (or stand-in).  `device`: where collective buffers live
         (the shard's GPU with the nccl backend, CPU with gloo).  `shard_io`: (save(shard, directory),
         load(directory) -> shard) used by save() / load(); default = persistence.save_index / load_index."""
@@ -49,10 +72,13 @@ class ShardedCollection:
         # with it add_texts() ships strings, each rank embeds the items it will own and appends them locally --
         # no vector leaves its GPU (SURVEY.md section 8e "Embed: no collective at all")
         self.encode_fn = encode_fn
+        self.encode_batch = max(1, int(encode_batch))
         self.group = group
+        self.control = control_group if control_group is not None else group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self._ctl_device = self.device if dist.get_backend(self.control) == "nccl" else torch.device("cpu")
         self.name = getattr(shard, "name", "sharded")
         self.metadata = getattr(shard, "metadata", None)
         self._owner: Dict[str, int] = {}          # rank 0 only: id -> owning rank
@@ -65,14 +91,21 @@ class ShardedCollection:
         self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ control plane -------
-    def _command(self, cmd: Optional[Dict[str, Any]]) -> Dict[str, Any]:
-        box = [cmd]
-        dist.broadcast_object_list(box, src=0, group=self.group)
+    def _header(self, words: Optional[Sequence[int]]) -> List[int]:
+        t = torch.zeros(8, dtype=torch.int64, device=self._ctl_device)
+        if words is not None:
+            t[: len(words)] = torch.tensor(list(words), dtype=torch.int64)
+        dist.broadcast(t, src=0, group=self.control)
+        return [int(x) for x in t.cpu()]
+
+    def _object(self, obj: Any) -> Any:
+        box = [obj]
+        dist.broadcast_object_list(box, src=0, group=self.control)
         return box[0]
 
     def _gather(self, obj: Any) -> Optional[List[Any]]:
         out = [None] * self.world if self.rank == 0 else None
-        dist.gather_object(obj, out, dst=0, group=self.group)
+        dist.gather_object(obj, out, dst=0, group=self.control)
         return out
 
     def _require_rank0(self):
@@ -80,132 +113,197 @@ class ShardedCollection:
             raise RuntimeError("collection methods are driven from rank 0; other ranks run worker_loop()")
 
     def worker_loop(self):
-        """Ranks != 0: execute rank 0's commands until it sends 'stop'."""
+        """Ranks != 0: execute rank 0's commands until it sends 'stop'.  A failing command has already reported its
+        error through the command's own status exchange; the loop goes on."""
         if self.rank == 0:
             raise RuntimeError("rank 0 drives the collection; worker_loop() is for the other ranks")
         while True:
-            cmd = self._command(None)
-            if cmd["op"] == "stop":
+            hdr = self._header(None)
+            if hdr[0] == OP_STOP:
                 return
-            self._execute(cmd)
+            try:
+                if hdr[0] == OP_QUERY:
+                    self._query_path(hdr, None, None)
+                else:
+                    self._execute(self._object(None))
+            except Exception:   # noqa: BLE001 -- the service must survive a bad request
+                logger.exception("rank %d: command failed", self.rank)
 
     def stop(self):
         self._require_rank0()
         with self._lock:
-            self._command({"op": "stop"})
+            self._header([OP_STOP])
 
     def _execute(self, cmd: Dict[str, Any]):
-        return getattr(self, "_do_" + cmd["op"])(cmd)
+        """local step on this rank -> one status gather -> finish on rank 0"""
+        try:
+            status = (True, getattr(self, "_local_" + cmd["op"])(cmd))
+        except Exception as e:   # noqa: BLE001
+            logger.exception("rank %d: local step of %r failed", self.rank, cmd["op"])
+            status = (False, f"{type(e).__name__}: {e}")
+        parts = self._gather(status)
+        if self.rank != 0:
+            return None
+        bad = [f"rank {g}: {p[1]}" for g, p in enumerate(parts) if not p[0]]
+        if bad:
+            raise ShardError(f"{cmd['op']} failed on " + "; ".join(bad))
+        return getattr(self, "_finish_" + cmd["op"])(cmd, [p[1] for p in parts])
 
     def _run(self, cmd: Dict[str, Any]):
         """rank 0: broadcast a command and take part in it, one at a time"""
         with self._lock:
-            return self._execute(self._command(cmd))
+            self._header([OP_OBJECT])
+            return self._execute(self._object(cmd))
 
     # ------------------------------------------------------------------ add -----------------
-    def add(self, embeddings, documents=None, metadatas=None, ids: Optional[Sequence[str]] = None):
+    def _assign(self, ids: Sequence[str]):
+        """shard assignment of a batch (emptiest shard first) WITHOUT touching the books: they are committed only
+        when every rank has stored its part, so a failed add can be retried (embedder.py:514-537 retries)"""
+        counts = list(self._counts)
+        seq = self._next_seq
+        seen, plan = set(), []
+        for i, s in enumerate(ids):
+            if s in self._owner or s in seen:    # duplicate id: ignored, as VectorIndex.add does
+                continue
+            seen.add(s)
+            r = int(np.argmin(counts))
+            counts[r] += 1
+            plan.append((i, r, seq))
+            seq += 1
+        return plan
+
+    def _add(self, payload_key: str, payload, documents, metadatas, ids):
         self._require_rank0()
-        n = len(embeddings)
+        n = len(payload)
         if ids is None or len(ids) != n:
-            raise ValueError("ids are required, one per embedding")
+            raise ValueError("ids are required, one per item")
         documents = list(documents) if documents is not None else [None] * n
         metadatas = list(metadatas) if metadatas is not None else [{} for _ in range(n)]
         with self._lock:
+            plan = self._assign(ids)
             parts: Dict[int, Dict[str, Any]] = {}
-            for i in range(n):
-                if ids[i] in self._owner:        # duplicate id: ignored, as VectorIndex.add does
-                    continue
-                r = int(np.argmin(self._counts))
-                self._owner[ids[i]] = r
-                self._counts[r] += 1
-                p = parts.setdefault(r, {"embeddings": [], "documents": [], "metadatas": [], "ids": [], "seqs": []})
-                p["seqs"].append(self._next_seq)
-                self._next_seq += 1
-                p["embeddings"].append(embeddings[i])
+            for i, r, seq in plan:
+                p = parts.setdefault(r, {payload_key: [], "documents": [], "metadatas": [], "ids": [], "seqs": []})
+                p["seqs"].append(seq)
+                p[payload_key].append(payload[i])
                 p["documents"].append(documents[i])
                 p["metadatas"].append(metadatas[i])
                 p["ids"].append(ids[i])
-            for p in parts.values():
-                p["embeddings"] = np.asarray(p["embeddings"], dtype=np.float32)
-            self._execute(self._command({"op": "add", "parts": parts}))
+            if payload_key == "embeddings":
+                for p in parts.values():
+                    p["embeddings"] = np.asarray(p["embeddings"], dtype=np.float32)
+            self._header([OP_OBJECT])
+            try:
+                self._execute(self._object({"op": "add", "parts": parts}))
+            except ShardError:
+                # some ranks stored their part: take the whole batch out again, then report
+                self._header([OP_OBJECT])
+                try:
+                    self._execute(self._object({"op": "delete", "ids": [ids[i] for i, _, _ in plan], "where": None,
+                                                "uncounted": True}))
+                finally:
+                    pass
+                raise
+            for i, r, seq in plan:
+                self._owner[ids[i]] = r
+                self._counts[r] += 1
+            if plan:
+                self._next_seq = plan[-1][2] + 1
+
+    def add(self, embeddings, documents=None, metadatas=None, ids: Optional[Sequence[str]] = None):
+        self._add("embeddings", embeddings, documents, metadatas, ids)
 
     def add_texts(self, texts: Sequence[str], documents=None, metadatas=None, ids: Optional[Sequence[str]] = None):
         """Ingest by text: every rank embeds and stores its own share (needs encode_fn on every rank)."""
-        self._require_rank0()
         if self.encode_fn is None:
             raise RuntimeError("add_texts needs an encode_fn on every rank")
-        n = len(texts)
-        if ids is None or len(ids) != n:
-            raise ValueError("ids are required, one per text")
-        documents = list(documents) if documents is not None else [None] * n
-        metadatas = list(metadatas) if metadatas is not None else [{} for _ in range(n)]
-        with self._lock:
-            parts: Dict[int, Dict[str, Any]] = {}
-            for i in range(n):
-                if ids[i] in self._owner:
-                    continue
-                r = int(np.argmin(self._counts))
-                self._owner[ids[i]] = r
-                self._counts[r] += 1
-                p = parts.setdefault(r, {"texts": [], "documents": [], "metadatas": [], "ids": [], "seqs": []})
-                p["seqs"].append(self._next_seq)
-                self._next_seq += 1
-                p["texts"].append(texts[i])
-                p["documents"].append(documents[i])
-                p["metadatas"].append(metadatas[i])
-                p["ids"].append(ids[i])
-            self._execute(self._command({"op": "add", "parts": parts}))
+        self._add("texts", texts, documents, metadatas, ids)
 
-    def _do_add(self, cmd):
+    def _local_add(self, cmd):
         p = cmd["parts"].get(self.rank)
         if p:
-            emb = p["embeddings"] if "embeddings" in p else np.asarray(self.encode_fn(p["texts"]), dtype=np.float32)
+            if "embeddings" in p:
+                emb = p["embeddings"]
+            else:   # this rank's share, in slices of the service's batch size (api.py:93): bounded workspace
+                texts = p["texts"]
+                emb = np.concatenate([np.asarray(self.encode_fn(texts[i:i + self.encode_batch]), dtype=np.float32)
+                                      for i in range(0, len(texts), self.encode_batch)])
             self.shard.add(emb, documents=p["documents"], metadatas=p["metadatas"], ids=p["ids"])
             for i, sq in zip(p["ids"], p["seqs"]):
                 self._seq_of[i] = sq
                 self._id_of[sq] = i
+        return None
+
+    def _finish_add(self, cmd, parts):
+        return None
 
     # ------------------------------------------------------------------ query ---------------
     def query(self, query_embeddings, n_results: int = 10, where: Optional[Dict[str, Any]] = None,
               include: Sequence[str] = ("metadatas", "documents", "distances")) -> Dict[str, Any]:
         self._require_rank0()
-        q = np.asarray(query_embeddings, dtype=np.float32)
-        if q.ndim == 1:
-            q = q[None, :]
-        return self._run({"op": "query", "q": q, "k": int(n_results), "where": where, "include": tuple(include)})
+        q = torch.as_tensor(np.ascontiguousarray(np.asarray(query_embeddings, dtype=np.float32)))
+        if q.dim() == 1:
+            q = q.unsqueeze(0)
+        mask = 0
+        for x in include:
+            mask |= _INCLUDE_BITS[x]
+        with self._lock:
+            hdr = self._header([OP_QUERY, q.shape[0], int(n_results), q.shape[1], 1 if where else 0, mask])
+            return self._query_path(hdr, q, where)
 
-    def _do_query(self, cmd):
-        q, k, where, include = cmd["q"], cmd["k"], cmd["where"], cmd["include"]
-        B = q.shape[0]
-        scores, rows = self.shard.search(q, k, where)            # [B, k'] desc, local rows, -1 = none
-        scores = torch.as_tensor(scores).to(torch.float32)
-        rows = torch.as_tensor(rows).to(torch.int64)
-        kk = scores.shape[1]
-        if kk < k:                                               # shard returned fewer columns than asked
-            pad = k - kk
-            scores = torch.cat([scores, torch.full((B, pad), float("-inf"), dtype=scores.dtype, device=scores.device)], 1)
-            rows = torch.cat([rows, torch.full((B, pad), -1, dtype=rows.dtype, device=rows.device)], 1)
-        # local row -> global sequence number (host tables; the serving loop is synchronous anyway)
-        rows_h = rows.cpu().numpy()
-        live = sorted({int(r) for r in rows_h.reshape(-1) if r >= 0})
-        seq_of_row = {r: self._seq_of[i] for r, i in zip(live, self.shard.ids_of_rows(live))}
-        seqs = np.array([[seq_of_row[int(r)] if r >= 0 else -1 for r in row] for row in rows_h], np.int64).reshape(B, k)
-        # ONE packed block per rank: [sequence numbers B*k i64 | scores B*k f32 | pad]
+    def _query_path(self, hdr, q, where):
+        _, B, k, d, has_where, mask = hdr[:6]
+        include = tuple(x for x, bit in _INCLUDE_BITS.items() if mask & bit)
+        # the query matrix: a tensor broadcast on the control group's device (no pickling)
+        qt = (q.to(self._ctl_device) if self.rank == 0 else torch.empty((B, d), dtype=torch.float32,
+                                                                       device=self._ctl_device))
+        dist.broadcast(qt, src=0, group=self.control)
+        if has_where:
+            where = self._object(where)
         nb = B * k
         nbytes = _native.packed_block_bytes(B, k)
         loc = torch.zeros(nbytes, dtype=torch.uint8)
-        loc[: nb * 8].view(torch.int64).copy_(torch.from_numpy(seqs).reshape(-1))
-        loc[nb * 8: nb * 12].view(torch.float32).copy_(scores.reshape(-1).cpu())
+        failure = None
+        try:
+            scores, rows = self.shard.search(qt.cpu().numpy() if self._ctl_device.type == "cpu" else qt, k, where)
+            scores = torch.as_tensor(scores).to(torch.float32)
+            rows = torch.as_tensor(rows).to(torch.int64)
+            kk = scores.shape[1]
+            if kk < k:                                           # shard returned fewer columns than asked
+                pad = k - kk
+                scores = torch.cat([scores, torch.full((B, pad), float("-inf"), dtype=scores.dtype, device=scores.device)], 1)
+                rows = torch.cat([rows, torch.full((B, pad), -1, dtype=rows.dtype, device=rows.device)], 1)
+            # local row -> global sequence number (host tables)
+            rows_h = rows.cpu().numpy()
+            live = sorted({int(r) for r in rows_h.reshape(-1) if r >= 0})
+            seq_of_row = {r: self._seq_of[i] for r, i in zip(live, self.shard.ids_of_rows(live))}
+            seqs = np.array([[seq_of_row[int(r)] if r >= 0 else -1 for r in row] for row in rows_h], np.int64).reshape(B, k)
+            # ONE packed block per rank: [sequence numbers B*k i64 | scores B*k f32 | pad]
+            loc[: nb * 8].view(torch.int64).copy_(torch.from_numpy(seqs).reshape(-1))
+            loc[nb * 8: nb * 12].view(torch.float32).copy_(scores.reshape(-1).cpu())
+        except Exception as e:   # noqa: BLE001 -- report through the data collective, stay in step
+            logger.exception("rank %d: local search failed", self.rank)
+            failure = f"{type(e).__name__}: {e}"
+            loc.zero_()
+            loc[: nb * 8].view(torch.int64).fill_(-1)
+            loc[nb * 8: nb * 12].view(torch.float32).fill_(float("-inf"))
+            loc[:8].view(torch.int64)[0] = _FAILED_ROW
         loc = loc.to(self.device)
         all_ = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
         dist.all_gather_into_tensor(all_, loc, group=self.group)
         host = all_.cpu()
+        heads = host.view(self.world, nbytes)[:, :8].contiguous().view(torch.int64).reshape(-1)
+        if bool((heads == _FAILED_ROW).any()):
+            msgs = self._gather(failure)        # every rank saw the marker: they all come here
+            if self.rank != 0:
+                return None
+            raise ShardError("query failed on " + "; ".join(f"rank {g}: {m}" for g, m in enumerate(msgs) if m))
         if k <= _native.MAX_K:
             top_s, top_r = _native.merge_topk_host_packed(host, self.world, B, k, k)
             top_s, top_r = top_s.numpy(), top_r.numpy()
         else:
             top_s, top_r = _merge_deep(host, self.world, B, k)
-        # describe the winning rows this rank owns
+        # describe the winning rows this rank owns (the only pickled part of a query: k rows' payload per query)
         mine: Dict[int, Dict[str, Any]] = {}
         owned = sorted({int(sq) for sq in top_r.reshape(-1) if sq >= 0 and int(sq) in self._id_of})
         if owned:
@@ -245,11 +343,10 @@ class ShardedCollection:
         return self._run({"op": "get", "ids": list(ids) if ids is not None else None, "where": where,
                           "include": tuple(include)})
 
-    def _do_get(self, cmd):
-        res = self.shard.get(ids=cmd["ids"], where=cmd["where"], include=cmd["include"])
-        parts = self._gather(res)
-        if self.rank != 0:
-            return None
+    def _local_get(self, cmd):
+        return self.shard.get(ids=cmd["ids"], where=cmd["where"], include=cmd["include"])
+
+    def _finish_get(self, cmd, parts):
         rows = []
         for p in parts:
             for j, i in enumerate(p["ids"]):
@@ -267,18 +364,19 @@ class ShardedCollection:
         self._require_rank0()
         return self._run({"op": "delete", "ids": list(ids) if ids is not None else None, "where": where})
 
-    def _do_delete(self, cmd):
+    def _local_delete(self, cmd):
         gone = self.shard.delete(ids=cmd["ids"], where=cmd["where"])
         for i in gone:
             self._id_of.pop(self._seq_of.pop(i), None)
-        parts = self._gather(gone)
-        if self.rank != 0:
-            return None
+        return gone
+
+    def _finish_delete(self, cmd, parts):
         out = []
         for g, p in enumerate(parts):
             for i in p:
-                self._owner.pop(i, None)
-                self._counts[g] -= 1
+                if not cmd.get("uncounted"):      # (roll-back of a failed add: those ids never reached the books)
+                    self._owner.pop(i, None)
+                    self._counts[g] -= 1
                 out.append(i)
         return sorted(out)
 
@@ -286,23 +384,26 @@ class ShardedCollection:
         self._require_rank0()
         return self._run({"op": "count"})
 
-    def _do_count(self, cmd):
-        parts = self._gather(self.shard.count())
-        return sum(parts) if self.rank == 0 else None
+    def _local_count(self, cmd):
+        return self.shard.count()
+
+    def _finish_count(self, cmd, parts):
+        return sum(parts)
 
     def reset(self):
         self._require_rank0()
-        with self._lock:
-            self._execute(self._command({"op": "reset"}))
-            self._owner.clear()
-            self._counts = [0] * self.world
-            self._next_seq = 0
+        self._run({"op": "reset"})
 
-    def _do_reset(self, cmd):
+    def _local_reset(self, cmd):
         self.shard.reset()
         self._seq_of.clear()
         self._id_of.clear()
+        return None
 
+    def _finish_reset(self, cmd, parts):
+        self._owner.clear()
+        self._counts = [0] * self.world
+        self._next_seq = 0
 
     # ------------------------------------------------------------------ save / load ---------
     def save(self, directory: str):
@@ -323,7 +424,7 @@ class ShardedCollection:
         dev = str(getattr(self.shard, "device", "cuda:0"))
         return persistence.save_index, (lambda d: persistence.load_index(d, device=dev))
 
-    def _do_save(self, cmd):
+    def _local_save(self, cmd):
         import json
         import os
 
@@ -332,12 +433,16 @@ class ShardedCollection:
         self._io()[0](self.shard, d)
         with open(os.path.join(d, "sequence.json"), "w", encoding="utf-8") as f:
             json.dump({"world": self.world, "seq_of": self._seq_of}, f)
-        self._gather(True)                       # everyone has written before rank 0 returns
-        if self.rank == 0:
-            with open(os.path.join(cmd["dir"], "sharded.json"), "w", encoding="utf-8") as f:
-                json.dump({"world": self.world, "next_seq": self._next_seq}, f)
+        return True
 
-    def _do_load(self, cmd):
+    def _finish_save(self, cmd, parts):      # every rank has written before rank 0 returns
+        import json
+        import os
+
+        with open(os.path.join(cmd["dir"], "sharded.json"), "w", encoding="utf-8") as f:
+            json.dump({"world": self.world, "next_seq": self._next_seq}, f)
+
+    def _local_load(self, cmd):
         import json
         import os
 
@@ -349,12 +454,16 @@ class ShardedCollection:
         self.shard = self._io()[1](d)
         self._seq_of = {i: int(sq) for i, sq in t["seq_of"].items()}
         self._id_of = {sq: i for i, sq in self._seq_of.items()}
-        parts = self._gather(list(self._seq_of))
-        if self.rank == 0:
-            with open(os.path.join(cmd["dir"], "sharded.json"), encoding="utf-8") as f:
-                self._next_seq = int(json.load(f)["next_seq"])
-            self._owner = {i: g for g, p in enumerate(parts) for i in p}
-            self._counts = [len(p) for p in parts]
+        return list(self._seq_of)
+
+    def _finish_load(self, cmd, parts):
+        import json
+        import os
+
+        with open(os.path.join(cmd["dir"], "sharded.json"), encoding="utf-8") as f:
+            self._next_seq = int(json.load(f)["next_seq"])
+        self._owner = {i: g for g, p in enumerate(parts) for i in p}
+        self._counts = [len(p) for p in parts]
 
 
 def _merge_deep(host: torch.Tensor, G: int, B: int, k: int):

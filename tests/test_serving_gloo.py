@@ -174,3 +174,87 @@ def test_sharded_collection_equals_single_collection(tmp_path, world):
     assert _close(got["manager"], want_m) and _close(got["manager_dp"], want_m)
     # data-parallel ingest: rank 0 encoded only its share of the 60 chunks (plus the queries)
     assert got["encode_calls_dp"] < got["encode_calls"] - 60 // world // 2
+
+
+# ---- a rank whose local step raises must not wedge the service (worker_loop had no error handling) -------
+class FlakyCollection(FakeCollection):
+    """FakeCollection whose search / add raise while `boom` is set (set through a special `where` / id)"""
+
+    def search(self, query_embeddings, n_results, where=None):
+        if where and where.get("boom") == self.rank_tag:
+            raise ValueError("unsupported where operator '$boom'")
+        return super().search(query_embeddings, n_results, where)
+
+    def add(self, embeddings, documents=None, metadatas=None, ids=None):
+        if any(i.startswith(f"explode_on_{self.rank_tag}") for i in ids):
+            raise MemoryError("shard is full")
+        return super().add(embeddings, documents, metadatas, ids)
+
+
+def _flaky_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multimodal_rag_amd.serving import ShardError
+
+        shard = FlakyCollection(D)
+        shard.rank_tag = rank
+        col = ShardedCollection(shard, control_group=dist.new_group(backend="gloo"))
+        if rank != 0:
+            col.worker_loop()
+            return
+        v, ids, metas, docs, q = data()
+        col.add(v[:80].tolist(), documents=docs[:80], metadatas=metas[:80], ids=ids[:80])
+        good = col.query(q.tolist(), n_results=5)
+        out = {}
+        for bad_rank in (0, 1):              # the driving rank's shard fails / a worker's shard fails
+            try:
+                col.query(q.tolist(), n_results=5, where={"boom": bad_rank})
+                out[f"query_{bad_rank}"] = "no error"
+            except ShardError as e:
+                out[f"query_{bad_rank}"] = str(e)
+            out[f"after_query_{bad_rank}"] = col.query(q.tolist(), n_results=5) == good      # still serving
+        # a failed add leaves nothing behind and can be retried (embedder.py:514-537 retries store calls)
+        n0 = col.count()
+        batch_ids = [f"explode_on_1_{i}" if i == 3 else f"fresh_{i}" for i in range(8)]
+        try:
+            col.add(v[80:88].tolist(), documents=docs[80:88], metadatas=metas[80:88], ids=batch_ids)
+            out["add"] = "no error"
+        except ShardError as e:
+            out["add"] = str(e)
+        out["count_after_failed_add"] = col.count() - n0
+        retry_ids = [f"fresh_{i}" for i in range(8)]
+        col.add(v[80:88].tolist(), documents=docs[80:88], metadatas=metas[80:88], ids=retry_ids)
+        out["count_after_retry"] = col.count() - n0
+        out["retry_rows_found"] = sorted(col.get(ids=retry_ids, include=())["ids"]) == sorted(retry_ids)
+        # interleaved add / delete / query: equal to ONE collection fed the same calls
+        single = FakeCollection(D)
+        single.add(v[:80].tolist(), documents=docs[:80], metadatas=metas[:80], ids=ids[:80])
+        single.add(v[80:88].tolist(), documents=docs[80:88], metadatas=metas[80:88], ids=retry_ids)
+        same = True
+        for step in range(6):
+            lo = 88 + 10 * step
+            for c in (col, single):
+                c.add(v[lo:lo + 10].tolist(), documents=docs[lo:lo + 10], metadatas=metas[lo:lo + 10], ids=ids[lo:lo + 10])
+                c.delete(ids=[ids[step * 7], ids[lo + 3]])
+            a, b = col.query(q.tolist(), n_results=5), single.query(q.tolist(), n_results=5)
+            same = same and a["ids"] == b["ids"] and np.allclose(a["distances"], b["distances"], atol=1e-6)
+            same = same and col.count() == single.count()
+        out["interleaved_equal"] = same
+        col.stop()
+        json.dump(out, open(os.path.join(out_dir, "flaky.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failing_rank_reports_and_service_survives(tmp_path):
+    mp.spawn(_flaky_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    out = json.load(open(tmp_path / "flaky.json"))
+    assert "rank 0: ValueError" in out["query_0"] and "rank 1" not in out["query_0"]
+    assert "rank 1: ValueError" in out["query_1"]
+    assert out["after_query_0"] and out["after_query_1"]
+    assert "rank 1: MemoryError" in out["add"]
+    assert out["count_after_failed_add"] == 0           # the half-stored batch was taken out again
+    assert out["count_after_retry"] == 8 and out["retry_rows_found"]
+    assert out["interleaved_equal"]
