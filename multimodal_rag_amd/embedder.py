@@ -1,22 +1,21 @@
-"""`EmbeddingManager`: drop-in mirror of the reference's app/utils/embedder.py for the hot path.
+"""`EmbeddingManager`: the reference's app/utils/embedder.py surface over the MI355X engines.
 
-Same class names, constructor and method signatures, return shapes, statistics keys, retry
-and error behaviour (each method cites the reference lines it follows).  What differs is what
-sits underneath:
+Class names, constructor and method signatures, return shapes, statistics keys, messages and the retry / error
+conventions are the reference's (each method names the lines it answers to).  The bodies are this package's own:
+vectors travel as numpy matrices between the encoder and the collection (Python float lists exist only where a
+signature returns them), every engine call goes through one retry helper, and both caches are one LRU class.
 
     reference                               here
-    SentenceTransformer(...).encode    ->   DeviceEncoder (HIP kernels, libmmrag.so)
-    chromadb collection (HNSW, CPU)    ->   VectorIndex  (fused MFMA GEMM + exact top-k, HBM)
+    SentenceTransformer(...).encode    ->   DeviceEncoder (HIP kernels, libmmrag.so)            engines.HipEngine
+    chromadb collection (HNSW, CPU)    ->   VectorIndex  (fused MFMA GEMM + exact top-k, HBM)   index.VectorIndex
 
 Deliberate differences:
-  * no "CUDA OOM -> fall back to CPU" path (embedder.py:231-243, :407-426): there is no second
-    backend, an out-of-memory error propagates;
-  * `batch_query` embeds the whole list as one batch and runs ONE [B, d] x [N, d]^T search
-    instead of N concurrent single queries (embedder.py:808-815); the result list has the same
-    shape, per-query failures are still reported as dicts carrying 'error';
-  * distances are cosine distances (1 - cos), the space of the collection the reference
-    committed;
-  * `get_stats()` is provided because api.py:472 calls it.
+  * no "CUDA OOM -> fall back to CPU" path (embedder.py:231-243, :407-426): there is no second backend, an
+    out-of-memory error propagates;
+  * `batch_query` embeds the whole list in one pass and runs ONE [B, d] x [N, d]^T search instead of N concurrent
+    single queries (embedder.py:808-815); same result list, per-query failures still become dicts carrying 'error';
+  * distances are cosine distances (1 - cos), the space of the collection the reference committed;
+  * `get_stats()` exists because api.py:472 calls it.
 """
 from __future__ import annotations
 
@@ -24,572 +23,319 @@ import asyncio
 import hashlib
 import logging
 import time
-from collections import OrderedDict
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
 from .config import settings
+from .engines import CLIP_MODEL_NAMES, ClipEngine, HipEngine, _is_clip_dir, load_item_image  # noqa: F401 (re-exported)
+from .hostutil import CountingLRU, call_with_retry
 
 logger = logging.getLogger(__name__)
 
+ITEM_KINDS = ("text", "table", "image")           # the kinds embed_and_store counts (embedder.py:477-479)
+RESULT_KEYS = ("ids", "distances", "metadatas", "documents")
+_COLLECTION_NOTE = {"description": "Multi-modal RAG embeddings"}
 
-class LRUCache:
-    """embedder.py:26-80 (same counters, same rounding)."""
+
+class LRUCache(CountingLRU):
+    """text -> embedding cache (embedder.py:26-80: maxsize 1000, hit/miss counters, hit rate rounded to 3 places)"""
 
     def __init__(self, maxsize: int = 1000):
-        self.cache: "OrderedDict[str, List[float]]" = OrderedDict()
-        self.maxsize = maxsize
-        self.hits = 0
-        self.misses = 0
-
-    def get(self, key: str) -> Optional[List[float]]:
-        if key in self.cache:
-            self.cache.move_to_end(key)
-            self.hits += 1
-            return self.cache[key]
-        self.misses += 1
-        return None
-
-    def put(self, key: str, value: List[float]):
-        if key in self.cache:
-            self.cache.move_to_end(key)
-        elif len(self.cache) >= self.maxsize:
-            self.cache.popitem(last=False)
-        self.cache[key] = value
-
-    def clear(self):
-        self.cache.clear()
-        self.hits = 0
-        self.misses = 0
-
-    def get_stats(self) -> Dict[str, Any]:
-        total = self.hits + self.misses
-        hit_rate = self.hits / total if total > 0 else 0.0
-        return {"size": len(self.cache), "maxsize": self.maxsize, "hits": self.hits, "misses": self.misses,
-                "hit_rate": round(hit_rate, 3)}
-
-
-class HipEngine:
-    """The MI355X engine pair behind EmbeddingManager: tokenizer + DeviceEncoder + VectorIndex
-    factory.  Constructing it without a GPU / without libmmrag.so raises."""
-
-    def __init__(self, model_name: str, device: Optional[str] = None):
-        import torch
-
-        from . import _native
-        from .encoder import PRESETS, DeviceEncoder
-        from .tokenizer import HashTokenizer, NativeWordPieceTokenizer
-
-        _native.lib()
-        if not torch.cuda.is_available():
-            raise RuntimeError("multimodal_rag_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
-        self.device = device if device and device != "cuda" else "cuda:0"
-        self.device_name = "cuda"
-        import os
-
-        model_dir = settings.MMRAG_MODEL_DIR
-        if model_dir:
-            self.encoder = DeviceEncoder.from_local_dir(model_dir, self.device)
-            vocab = os.path.join(model_dir, "vocab.txt")
-            self.tokenizer = (NativeWordPieceTokenizer.from_vocab_file(vocab) if os.path.exists(vocab)
-                              else HashTokenizer(self.encoder.cfg.vocab))
-        else:
-            if model_name not in PRESETS:
-                raise ValueError(f"unknown model {model_name!r}: give MMRAG_MODEL_DIR or one of {sorted(PRESETS)}")
-            logger.warning("No local checkpoint (MMRAG_MODEL_DIR unset): %s architecture with seeded random "
-                           "weights and the stand-in hash tokenizer", model_name)
-            self.encoder = DeviceEncoder.random_init(PRESETS[model_name], settings.MMRAG_WEIGHT_SEED, self.device)
-            self.tokenizer = HashTokenizer(self.encoder.cfg.vocab)
-        self.dim = self.encoder.dim
-        self.max_seq_length = self.encoder.cfg.max_seq_length
-        self._torch = torch
-
-    def encode(self, texts: List[str]) -> np.ndarray:
-        if hasattr(self.tokenizer, "encode_batch_arrays"):   # native, multi-threaded tokenizer
-            out = self.encoder.encode_id_rows(*self.tokenizer.encode_batch_arrays(texts, self.max_seq_length))
-        else:
-            out = self.encoder.encode_ids([self.tokenizer.encode(t, self.max_seq_length) for t in texts])
-        return out.cpu().numpy()
-
-    def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):
-        from .index import VectorIndex
-
-        dtype = {"float16": self._torch.float16, "float32": self._torch.float32,
-                 "bfloat16": self._torch.bfloat16}[settings.MMRAG_INDEX_DTYPE]
-        return VectorIndex(self.dim, dtype=dtype, device=self.device, name=name, metadata=metadata)
-
-    def release(self):
-        self._torch.cuda.empty_cache()
-
-
-CLIP_MODEL_NAMES = ("openai/clip-vit-base-patch32", "clip-ViT-B-32", "ViT-B/32")
-
-
-class ClipEngine:
-    """BASELINE config 4 (joint text/image space; the reference never loads CLIP): the same
-    engine interface as HipEngine over both CLIP towers.  Text goes through the byte-level BPE when the
-    model directory holds vocab.json + merges.txt; `encode_images` takes decoded RGB arrays of any size
-    (HIP resize + centre crop, then the vision tower)."""
-
-    def __init__(self, model_name: str, device: Optional[str] = None):
-        import os
-
-        import torch
-
-        from . import _native
-        from .clip import VIT_B32, ClipImagePreprocessor, DeviceClip
-        from .tokenizer import ClipBpeTokenizer
-
-        _native.lib()
-        if not torch.cuda.is_available():
-            raise RuntimeError("multimodal_rag_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
-        self.device = device if device and device != "cuda" else "cuda:0"
-        self.device_name = "cuda"
-        model_dir = settings.MMRAG_MODEL_DIR
-        self.tokenizer = None
-        if model_dir:
-            self.clip = DeviceClip.from_local_dir(model_dir, self.device)
-            vj, mt = os.path.join(model_dir, "vocab.json"), os.path.join(model_dir, "merges.txt")
-            if os.path.exists(vj) and os.path.exists(mt):
-                self.tokenizer = ClipBpeTokenizer.from_files(vj, mt, self.clip.cfg.t_max_pos)
-        else:
-            logger.warning("No local checkpoint (MMRAG_MODEL_DIR unset): CLIP ViT-B/32 architecture with seeded "
-                           "random weights and stand-in token ids (%s)", model_name)
-            self.clip = DeviceClip.random_init(VIT_B32, settings.MMRAG_WEIGHT_SEED, self.device)
-        self.preprocess = ClipImagePreprocessor(self.device, self.clip.cfg.image)
-        self.dim = self.clip.dim
-        self.max_seq_length = self.clip.cfg.t_max_pos
-        self._torch = torch
-
-    def _ids(self, text: str) -> List[int]:
-        if self.tokenizer is not None:
-            return self.tokenizer.encode(text, self.max_seq_length)
-        # stand-in (no vocabulary available): hashed word ids below the two special tokens
-        c = self.clip.cfg
-        words = text.lower().split()[: self.max_seq_length - 2]
-        body = [int.from_bytes(hashlib.md5(w.encode()).digest()[:4], "little") % (c.vocab - 2) for w in words]
-        return [c.vocab - 2] + body + [c.eos_id]
-
-    def encode(self, texts: List[str]) -> np.ndarray:
-        return self.clip.encode_text_ids([self._ids(t) for t in texts]).cpu().numpy()
-
-    def encode_images(self, images: List[np.ndarray]) -> np.ndarray:
-        return self.clip.encode_images(self.preprocess(images)).cpu().numpy()
-
-    def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):
-        from .index import VectorIndex
-
-        dtype = {"float16": self._torch.float16, "float32": self._torch.float32,
-                 "bfloat16": self._torch.bfloat16}[settings.MMRAG_INDEX_DTYPE]
-        return VectorIndex(self.dim, dtype=dtype, device=self.device, name=name, metadata=metadata)
-
-    def release(self):
-        self._torch.cuda.empty_cache()
-
-
-def _is_clip_dir(model_dir: str) -> bool:
-    import json
-    import os
-
-    cfg = os.path.join(model_dir, "config.json") if model_dir else ""
-    if not cfg or not os.path.exists(cfg):
-        return False
-    with open(cfg) as f:
-        return json.load(f).get("model_type") == "clip"
-
-
-def load_item_image(item: Dict[str, Any]) -> Optional[np.ndarray]:
-    """RGB uint8 [H, W, 3] pixels of an image item: `path` (parser output, reference parser.py image items) or
-    `raw` holding a base64 PNG/JPEG (summarizer.py:629-655 schema).  None when neither decodes."""
-    import base64
-    import io
-    import os
-
-    try:
-        from PIL import Image
-    except ImportError:
-        return None
-    try:
-        path = item.get("path")
-        if path and os.path.exists(path):
-            return np.asarray(Image.open(path).convert("RGB"))
-        raw = item.get("raw")
-        if isinstance(raw, str) and len(raw) > 64:
-            data = raw.split(",", 1)[1] if raw.startswith("data:") else raw
-            return np.asarray(Image.open(io.BytesIO(base64.b64decode(data))).convert("RGB"))
-    except Exception as e:  # undecodable image: fall back to embedding its summary text
-        logger.warning("image item %s: cannot decode pixels (%s); embedding its summary instead", item.get("id"), e)
-    return None
+        super().__init__(maxsize)
 
 
 class EmbeddingManager:
     """embedder.py:83-930."""
 
-    def __init__(
-        self,
-        batch_size: int = 32,
-        enable_cache: bool = True,
-        cache_size: int = 1000,
-        device: Optional[str] = None,
-        max_retries: int = 3,
-        enable_progress_logging: bool = True,
-        *,
-        engine: Any = None,
-    ):
+    def __init__(self, batch_size: int = 32, enable_cache: bool = True, cache_size: int = 1000,
+                 device: Optional[str] = None, max_retries: int = 3, enable_progress_logging: bool = True,
+                 *, engine: Any = None):
         self.batch_size = batch_size
         self.enable_cache = enable_cache
         self.max_retries = max_retries
         self.enable_progress_logging = enable_progress_logging
-
+        self.device = device
         self.client = None
         self.collection = None
         self.text_model = None
-        self.device = device
         self.is_initialized = False
-        self._engine = engine
-        self._encode_lock = asyncio.Lock()
-        self._sleep = asyncio.sleep
-
         self.cache = LRUCache(maxsize=cache_size) if enable_cache else None
-        self.stats = {
-            "total_embeddings_created": 0,
-            "total_items_stored": 0,
-            "total_queries": 0,
-            "cache_hits": 0,
-            "cache_misses": 0,
-        }
+        self.stats = dict.fromkeys(("total_embeddings_created", "total_items_stored", "total_queries", "cache_hits",
+                                    "cache_misses"), 0)
+        self._engine = engine
+        self._dispatcher = None
+        self._encode_lock = asyncio.Lock()       # one encoder pass at a time from this event loop
+        self._sleep = asyncio.sleep              # (tests swap the back-off sleep out)
 
     # ------------------------------------------------------------------ lifecycle -----------
     async def initialize(self):
-        """embedder.py:152-193: collection first, then the model."""
+        """embedder.py:152-248: bring up the model and the collection (idempotent)."""
         if self.is_initialized:
             return
         try:
-            await self._initialize_model()
-            self.client = self._engine
-            self.collection = self._engine.new_collection(
-                settings.CHROMA_COLLECTION_NAME, {"description": "Multi-modal RAG embeddings"})
+            if self._engine is None:
+                name = settings.SENTENCE_TRANSFORMER_MODEL
+                joint = name in CLIP_MODEL_NAMES or _is_clip_dir(settings.MMRAG_MODEL_DIR)
+                self._engine = await asyncio.to_thread(ClipEngine if joint else HipEngine, name, self.device)
+            self.text_model = self.client = self._engine
+            self.device = getattr(self._engine, "device_name", self.device or "cuda")
+            self.collection = self._engine.new_collection(settings.CHROMA_COLLECTION_NAME, dict(_COLLECTION_NOTE))
             self.is_initialized = True
             logger.info("EmbeddingManager initialized (device=%s, dim=%d)", self.device, self.get_embedding_dimension())
         except Exception as e:
             logger.error("Failed to initialize EmbeddingManager: %s", e, exc_info=True)
             raise
 
-    async def _initialize_model(self):
-        """embedder.py:195-243 minus the CPU fallback."""
-        if self._engine is None:
-            name = settings.SENTENCE_TRANSFORMER_MODEL
-            factory = ClipEngine if (name in CLIP_MODEL_NAMES or _is_clip_dir(settings.MMRAG_MODEL_DIR)) else HipEngine
-            self._engine = await asyncio.to_thread(factory, name, self.device)
-        self.text_model = self._engine
-        self.device = getattr(self._engine, "device_name", self.device or "cuda")
+    async def _ready(self):
+        if not self.is_initialized:
+            await self.initialize()
 
     async def cleanup(self):
         """embedder.py:250-264."""
-        if getattr(self, "_dispatcher", None) is not None:
+        if self._dispatcher is not None:
             await self._dispatcher.stop()
             self._dispatcher = None
-        if self._engine is not None and hasattr(self._engine, "release"):
-            self._engine.release()
-        self.client = None
-        self.collection = None
-        self.text_model = None
+        release = getattr(self._engine, "release", None)
+        if release is not None:
+            release()
+        self.client = self.collection = self.text_model = None
         self.is_initialized = False
         if self.cache:
             self.cache.clear()
 
+    def _engine_call(self, what: str, fn, *args, **kwargs):
+        return call_with_retry(what, fn, *args, attempts=self.max_retries, sleep=self._sleep, log=logger, **kwargs)
+
     # ------------------------------------------------------------------ embed ---------------
+    def _get_cache_key(self, text: str) -> str:
+        """embedder.py:736-742."""
+        return hashlib.md5(text.encode("utf-8")).hexdigest()
+
+    async def _embed_matrix(self, texts: Sequence[str], rows_per_pass: int) -> np.ndarray:
+        """[len(texts), dim] float32: cached rows reused, the rest encoded `rows_per_pass` texts at a time, every
+        row at its text's position (embedder.py:301-332 partitions, encodes the misses, caches them, restores order).
+        A cached value of length 0 counts as a miss, as the reference's truthiness test does (:306)."""
+        rows: List[Optional[np.ndarray]] = [None] * len(texts)
+        todo: List[int] = []
+        keys: Dict[int, str] = {}
+        for at, text in enumerate(texts):
+            if self.cache:
+                keys[at] = self._get_cache_key(text)
+                seen = self.cache.get(keys[at])
+                if seen is not None and len(seen):
+                    rows[at] = np.asarray(seen, dtype=np.float32)
+                    continue
+            todo.append(at)
+        for lo in range(0, len(todo), max(1, rows_per_pass)):
+            part = todo[lo: lo + max(1, rows_per_pass)]
+            async with self._encode_lock:
+                fresh = await asyncio.to_thread(self.text_model.encode, [texts[at] for at in part])
+            fresh = np.asarray(fresh, dtype=np.float32)
+            for at, row in zip(part, fresh):
+                rows[at] = row
+                if self.cache:
+                    self.cache.put(keys[at], row)
+        self.stats["total_embeddings_created"] += len(todo)
+        if self.cache:
+            self.stats["cache_hits"], self.stats["cache_misses"] = self.cache.hits, self.cache.misses
+        if not rows:
+            return np.zeros((0, self.get_embedding_dimension()), dtype=np.float32)
+        return np.stack(rows)
+
     async def embed_texts_batch(self, texts: List[str], show_progress: bool = None) -> List[List[float]]:
-        """embedder.py:266-347."""
-        if not self.is_initialized:
-            await self.initialize()
+        """embedder.py:266-383: lists of Python floats, input order, misses encoded in slices of `batch_size`."""
+        await self._ready()
         if not texts:
             return []
-        if show_progress is None:
-            show_progress = len(texts) > 100 and self.enable_progress_logging
-        if show_progress:
+        loud = (len(texts) > 100 and self.enable_progress_logging) if show_progress is None else show_progress
+        if loud:
             logger.info("Creating embeddings for %d texts...", len(texts))
-
-        embeddings = []
-        texts_to_embed = []
-        cache_indices = []
-        if self.cache:
-            for idx, text in enumerate(texts):
-                cached_embedding = self.cache.get(self._get_cache_key(text))
-                if cached_embedding:  # (an empty list is treated as a miss, as in the reference :306)
-                    embeddings.append((idx, cached_embedding))
-                else:
-                    texts_to_embed.append(text)
-                    cache_indices.append(idx)
-        else:
-            texts_to_embed = texts
-            cache_indices = list(range(len(texts)))
-
-        if texts_to_embed:
-            new_embeddings = await self._encode_batch(texts_to_embed, show_progress=show_progress)
-            for idx, text, embedding in zip(cache_indices, texts_to_embed, new_embeddings):
-                if self.cache:
-                    self.cache.put(self._get_cache_key(text), embedding)
-                embeddings.append((idx, embedding))
-
-        embeddings.sort(key=lambda x: x[0])
-        result = [emb for _, emb in embeddings]
-
-        self.stats["total_embeddings_created"] += len(texts_to_embed)
-        if self.cache:
-            cache_stats = self.cache.get_stats()
-            self.stats["cache_hits"] = cache_stats["hits"]
-            self.stats["cache_misses"] = cache_stats["misses"]
-        if show_progress:
-            logger.info("Created %d new embeddings, %d from cache", len(texts_to_embed),
-                        len(texts) - len(texts_to_embed))
-        return result
-
-    async def _encode_batch(self, texts: List[str], show_progress: bool = False) -> List[List[float]]:
-        """embedder.py:349-383: sequential slices of `batch_size`, each in a worker thread."""
-        total_batches = (len(texts) + self.batch_size - 1) // self.batch_size
-        all_embeddings: List[List[float]] = []
-        for batch_idx in range(total_batches):
-            start_idx = batch_idx * self.batch_size
-            batch_texts = texts[start_idx: min(start_idx + self.batch_size, len(texts))]
-            async with self._encode_lock:  # one encoder pass at a time (shared workspace)
-                batch_embeddings = await asyncio.to_thread(self._encode_sync, batch_texts)
-            all_embeddings.extend(batch_embeddings)
-        return all_embeddings
-
-    def _encode_sync(self, texts: List[str]) -> List[List[float]]:
-        """embedder.py:385-405; OOM fallback (:407-426) deliberately absent."""
-        embeddings = self.text_model.encode(texts)
-        return np.asarray(embeddings, dtype=np.float32).tolist()
+        before = self.stats["total_embeddings_created"]
+        matrix = await self._embed_matrix(texts, self.batch_size)
+        if loud:
+            made = self.stats["total_embeddings_created"] - before
+            logger.info("Created %d new embeddings, %d from cache", made, len(texts) - made)
+        return matrix.tolist()
 
     # ------------------------------------------------------------------ store ---------------
     async def embed_and_store(self, summaries: List[Dict[str, Any]], doc_id: str) -> Dict[str, int]:
-        """embedder.py:428-500."""
-        if not self.is_initialized:
-            await self.initialize()
+        """embedder.py:428-500: embed every item's `summary`, store it under f"{doc_id}_{item id}"."""
+        await self._ready()
+        counts = dict.fromkeys(ITEM_KINDS, 0)
         if not summaries:
             logger.warning("No summaries provided for embedding")
-            return {"text": 0, "table": 0, "image": 0}
-
-        start_time = time.time()
-        texts = [item["summary"] for item in summaries]
-        if getattr(self.collection, "encode_fn", None) is not None and not hasattr(self._engine, "encode_images"):
-            # multi-GPU serving loop with an encoder on every rank: ship the strings, each rank embeds and stores
-            # the items it owns (serving.ShardedCollection.add_texts)
-            counts = {"text": 0, "table": 0, "image": 0}
-            for item in summaries:
-                if item["type"] in counts:
-                    counts[item["type"]] += 1
-            await asyncio.to_thread(
-                self.collection.add_texts, texts, documents=texts,
-                metadatas=[{"doc_id": doc_id, "item_id": it["id"], "type": it["type"]} for it in summaries],
-                ids=[f"{doc_id}_{it['id']}" for it in summaries])
-            self.stats["total_items_stored"] += len(summaries)
-            logger.info("Stored %d embeddings for doc %s (data-parallel ingest) in %.2fs", len(summaries), doc_id,
-                        time.time() - start_time)
             return counts
-        embeddings = await self.embed_texts_batch(texts, show_progress=True)
-        if hasattr(self._engine, "encode_images") and settings.MMRAG_EMBED_IMAGE_PIXELS:
-            # joint-space engines (CLIP, BASELINE config 4): image items are embedded from their pixels
-            pix = [(i, load_item_image(it)) for i, it in enumerate(summaries) if it.get("type") == "image"]
-            pix = [(i, p) for i, p in pix if p is not None]
-            if pix:
-                async with self._encode_lock:
-                    vecs = await asyncio.to_thread(self._engine.encode_images, [p for _, p in pix])
-                for (i, _), v in zip(pix, vecs):
-                    embeddings[i] = v.tolist()
-
-        documents, metadatas, ids = [], [], []
-        counts = {"text": 0, "table": 0, "image": 0}
-        for item, _ in zip(summaries, embeddings):
-            documents.append(item["summary"])
-            metadatas.append({"doc_id": doc_id, "item_id": item["id"], "type": item["type"]})
-            ids.append(f"{doc_id}_{item['id']}")
-            if item["type"] in counts:
+        t0 = time.time()
+        texts = [item["summary"] for item in summaries]
+        ids = [f"{doc_id}_{item['id']}" for item in summaries]
+        metas = [{"doc_id": doc_id, "item_id": item["id"], "type": item["type"]} for item in summaries]
+        for item in summaries:
+            if item["type"] in counts:           # other kinds are stored but not counted (:477-479)
                 counts[item["type"]] += 1
-
-        await self._store_with_retry(embeddings=embeddings, documents=documents, metadatas=metadatas, ids=ids)
+        joint = hasattr(self._engine, "encode_images")
+        if getattr(self.collection, "encode_fn", None) is not None and not joint:
+            # multi-GPU serving loop with an encoder on every rank: ship the strings, each rank embeds and stores the
+            # items it owns (serving.ShardedCollection.add_texts) -- no vector leaves its GPU
+            await asyncio.to_thread(self.collection.add_texts, texts, documents=texts, metadatas=metas, ids=ids)
+        else:
+            matrix = await self._embed_matrix(texts, self.batch_size)
+            if joint and settings.MMRAG_EMBED_IMAGE_PIXELS:
+                # joint-space engines (CLIP, BASELINE config 4): image items are embedded from their pixels
+                pixels = {at: load_item_image(item) for at, item in enumerate(summaries) if item.get("type") == "image"}
+                pixels = {at: px for at, px in pixels.items() if px is not None}
+                if pixels:
+                    async with self._encode_lock:
+                        vecs = await asyncio.to_thread(self._engine.encode_images, list(pixels.values()))
+                    matrix[list(pixels)] = np.asarray(vecs, dtype=np.float32)
+            await self._store_with_retry(embeddings=matrix, documents=texts, metadatas=metas, ids=ids)
         self.stats["total_items_stored"] += len(summaries)
-        logger.info("Stored %d embeddings for doc %s (text: %d, table: %d, image: %d) in %.2fs", len(embeddings),
-                    doc_id, counts["text"], counts["table"], counts["image"], time.time() - start_time)
+        logger.info("Stored %d embeddings for doc %s (text: %d, table: %d, image: %d) in %.2fs", len(summaries), doc_id,
+                    counts["text"], counts["table"], counts["image"], time.time() - t0)
         return counts
 
     async def _store_with_retry(self, embeddings, documents, metadatas, ids):
-        """embedder.py:502-537: 3 attempts, 2**attempt seconds apart."""
-        for attempt in range(self.max_retries):
-            try:
-                await asyncio.to_thread(self.collection.add, embeddings=embeddings, documents=documents,
-                                        metadatas=metadatas, ids=ids)
-                return
-            except Exception as e:
-                if attempt == self.max_retries - 1:
-                    logger.error("Failed to store after %d attempts: %s", self.max_retries, e)
-                    raise
-                wait_time = 2 ** attempt
-                logger.warning("Store attempt %d failed: %s. Retrying in %ds...", attempt + 1, e, wait_time)
-                await self._sleep(wait_time)
+        """embedder.py:502-537."""
+        await self._engine_call("Store", self.collection.add, embeddings=embeddings, documents=documents,
+                                metadatas=metadatas, ids=ids)
 
     # ------------------------------------------------------------------ query ---------------
     def enable_dynamic_batching(self, max_batch: int = 256, max_wait_ms: float = 2.0):
-        """Route query() through a micro-batching dispatcher (not in the reference):
-        concurrent single queries are served by one batched encode + one batched search."""
+        """Route query() through a micro-batching dispatcher (not in the reference): concurrent single
+        queries are served by one batched encode + one batched search."""
         from .dispatcher import QueryDispatcher
 
         self._dispatcher = QueryDispatcher(self.batch_query, max_batch=max_batch, max_wait_ms=max_wait_ms)
         return self._dispatcher
 
-    async def query(self, query_text: str, n_results: int = 5, filter_dict: Optional[Dict] = None) -> Dict[str, Any]:
-        """embedder.py:539-583."""
-        if not self.is_initialized:
-            await self.initialize()
-        if not query_text or not query_text.strip():
-            raise ValueError("Query text cannot be empty")
-        if getattr(self, "_dispatcher", None) is not None:
-            return await self._dispatcher.submit(query_text, n_results, filter_dict)
-        try:
-            query_embeddings = await self.embed_texts_batch([query_text])
-            results = await self._query_with_retry(query_embedding=query_embeddings[0], n_results=n_results,
-                                                   filter_dict=filter_dict)
-            self.stats["total_queries"] += 1
-            return results
-        except Exception as e:
-            logger.error("Query failed: %s", e, exc_info=True)
-            raise
+    async def _search(self, matrix: np.ndarray, n_results: int, filter_dict: Optional[Dict]) -> List[Dict[str, Any]]:
+        """one collection.query for all rows of `matrix` (embedder.py:595-601), split into one dict per query (:604-609)"""
+        res = await self._engine_call("Query", self.collection.query, query_embeddings=matrix, n_results=n_results,
+                                      where=filter_dict, include=["metadatas", "documents", "distances"])
+        out = []
+        for b in range(len(matrix)):
+            out.append({key: (res[key][b] if res.get(key) else []) for key in RESULT_KEYS})
+        return out
 
     async def _query_with_retry(self, query_embedding: List[float], n_results: int,
                                 filter_dict: Optional[Dict]) -> Dict[str, Any]:
         """embedder.py:585-617."""
-        for attempt in range(self.max_retries):
-            try:
-                results = await asyncio.to_thread(
-                    self.collection.query, query_embeddings=[query_embedding], n_results=n_results,
-                    where=filter_dict, include=["metadatas", "documents", "distances"])
-                return {
-                    "ids": results["ids"][0] if results["ids"] else [],
-                    "distances": results["distances"][0] if results["distances"] else [],
-                    "metadatas": results["metadatas"][0] if results["metadatas"] else [],
-                    "documents": results["documents"][0] if results["documents"] else [],
-                }
-            except Exception as e:
-                if attempt == self.max_retries - 1:
-                    raise
-                wait_time = 2 ** attempt
-                logger.warning("Query attempt %d failed: %s. Retrying in %ds...", attempt + 1, e, wait_time)
-                await self._sleep(wait_time)
+        return (await self._search(np.asarray([query_embedding], dtype=np.float32), n_results, filter_dict))[0]
+
+    async def query(self, query_text: str, n_results: int = 5, filter_dict: Optional[Dict] = None) -> Dict[str, Any]:
+        """embedder.py:539-583."""
+        await self._ready()
+        if not query_text or not query_text.strip():
+            raise ValueError("Query text cannot be empty")
+        if self._dispatcher is not None:
+            return await self._dispatcher.submit(query_text, n_results, filter_dict)
+        try:
+            hit = (await self._search(await self._embed_matrix([query_text], 1), n_results, filter_dict))[0]
+        except Exception as e:
+            logger.error("Query failed: %s", e, exc_info=True)
+            raise
+        self.stats["total_queries"] += 1
+        return hit
 
     async def batch_query(self, queries: List[str], n_results: int = 5,
                           filter_dict: Optional[Dict] = None) -> List[Dict[str, Any]]:
-        """embedder.py:784-832, as ONE batched search (see module docstring)."""
-        if not queries:
-            return []
-        if not self.is_initialized:
-            await self.initialize()
-        empty = {"ids": [], "distances": [], "metadatas": [], "documents": []}
-        final: List[Optional[Dict[str, Any]]] = [None] * len(queries)
-        good = []
-        for i, q in enumerate(queries):
-            if not q or not q.strip():
-                final[i] = {**empty, "error": "Query text cannot be empty"}
-            else:
-                good.append(i)
-        if good:
+        """embedder.py:784-832: one result dict per query, input order; a query that cannot be answered gets a dict
+        with empty lists and an 'error' message instead of an exception (:817-830)."""
+        await self._ready()
+
+        def failed(why: str) -> Dict[str, Any]:
+            return {**{key: [] for key in RESULT_KEYS}, "error": why}
+
+        answers: List[Optional[Dict[str, Any]]] = [None] * len(queries)
+        live = [at for at, q in enumerate(queries) if q and q.strip()]
+        for at in set(range(len(queries))) - set(live):
+            answers[at] = failed("Query text cannot be empty")
+        if live:
             try:
-                embs = await self.embed_texts_batch([queries[i] for i in good])
-                res = None
-                for attempt in range(self.max_retries):
-                    try:
-                        res = await asyncio.to_thread(
-                            self.collection.query, query_embeddings=embs, n_results=n_results, where=filter_dict,
-                            include=["metadatas", "documents", "distances"])
-                        break
-                    except Exception:
-                        if attempt == self.max_retries - 1:
-                            raise
-                        await self._sleep(2 ** attempt)
-                for j, i in enumerate(good):
-                    final[i] = {"ids": res["ids"][j], "distances": res["distances"][j],
-                                "metadatas": res["metadatas"][j], "documents": res["documents"][j]}
-                    self.stats["total_queries"] += 1
+                matrix = await self._embed_matrix([queries[at] for at in live], len(live))
+                for at, hit in zip(live, await self._search(matrix, n_results, filter_dict)):
+                    answers[at] = hit
+                self.stats["total_queries"] += len(live)
             except Exception as e:
                 logger.error("Batch query failed: %s", e)
-                for i in good:
-                    final[i] = {**empty, "error": str(e)}
-        return final  # type: ignore[return-value]
+                for at in live:
+                    answers[at] = failed(str(e))
+        return answers  # type: ignore[return-value]
+
+    async def get_similar_documents(self, doc_id: str, item_id: str, n_results: int = 5) -> Dict[str, Any]:
+        """embedder.py:861-930: the stored vector of one item searched for its n nearest OTHER items."""
+        await self._ready()
+        try:
+            me = f"{doc_id}_{item_id}"
+            stored = await asyncio.to_thread(self.collection.get, ids=[me], include=["embeddings", "documents"])
+            if not stored["ids"]:
+                raise ValueError(f"Item not found: {me}")
+            near = await asyncio.to_thread(self.collection.query, query_embeddings=[stored["embeddings"][0]],
+                                           n_results=n_results + 1, include=["metadatas", "documents", "distances"])
+            others = [j for j, found in enumerate(near["ids"][0]) if found != me][:n_results]
+            return {key: [near[key][0][j] for j in others] for key in RESULT_KEYS}
+        except Exception as e:
+            logger.error("Failed to find similar documents: %s", e)
+            raise
+
+    async def rerank_results(self, query_text: str, results: Dict[str, Any],
+                             top_k: Optional[int] = None) -> Dict[str, Any]:
+        """embedder.py:834-859: the reference's placeholder -- no re-ranking, only truncation to top_k."""
+        logger.warning("Re-ranking not implemented yet")
+        if top_k and top_k < len(results["ids"]):
+            return {key: results[key][:top_k] for key in RESULT_KEYS}
+        return results
 
     # ------------------------------------------------------------------ maintenance ---------
     async def delete_document(self, doc_id: str):
-        """embedder.py:619-656."""
-        if not self.is_initialized:
-            await self.initialize()
-        for attempt in range(self.max_retries):
-            try:
-                results = await asyncio.to_thread(self.collection.get, where={"doc_id": doc_id}, include=[])
-                if results["ids"]:
-                    await asyncio.to_thread(self.collection.delete, ids=results["ids"])
-                    logger.info("Deleted %d embeddings for doc %s", len(results["ids"]), doc_id)
-                else:
-                    logger.warning("No embeddings found for doc %s", doc_id)
-                return
-            except Exception as e:
-                if attempt == self.max_retries - 1:
-                    logger.error("Failed to delete document %s: %s", doc_id, e)
-                    raise
-                await self._sleep(2 ** attempt)
+        """embedder.py:619-656: drop every row whose metadata carries this doc_id."""
+        await self._ready()
+        gone = await self._engine_call(f"Delete of document {doc_id}", self.collection.delete, where={"doc_id": doc_id})
+        if gone:
+            logger.info("Deleted %d embeddings for doc %s", len(gone), doc_id)
+        else:
+            logger.warning("No embeddings found for doc %s", doc_id)
 
     async def delete_all_documents(self):
-        """embedder.py:658-688: drop and re-create the collection, clear the cache."""
-        if not self.is_initialized:
-            await self.initialize()
+        """embedder.py:658-688: a fresh collection under the same name, and an empty cache."""
+        await self._ready()
         try:
-            self.collection = await asyncio.to_thread(
-                self._engine.new_collection, settings.CHROMA_COLLECTION_NAME,
-                {"description": "Multi-modal RAG embeddings"})
-            if self.cache:
-                self.cache.clear()
+            self.collection = await asyncio.to_thread(self._engine.new_collection, settings.CHROMA_COLLECTION_NAME,
+                                                      dict(_COLLECTION_NOTE))
         except Exception as e:
             logger.error("Failed to delete all documents: %s", e)
             raise
+        if self.cache:
+            self.cache.clear()
 
     async def get_collection_stats(self) -> Dict[str, Any]:
-        """embedder.py:690-728 (same keys)."""
-        if not self.is_initialized:
-            await self.initialize()
+        """embedder.py:690-728 (same keys; an engine failure is reported in the dict, not raised)."""
+        await self._ready()
         try:
-            count = await asyncio.to_thread(self.collection.count)
-            stats = {
+            report = {
                 "name": settings.CHROMA_COLLECTION_NAME,
-                "count": count,
+                "count": await asyncio.to_thread(self.collection.count),
                 "model": settings.SENTENCE_TRANSFORMER_MODEL,
                 "device": self.device,
                 "embedding_dim": self.get_embedding_dimension(),
                 "batch_size": self.batch_size,
-                "stats": {
-                    "total_embeddings_created": self.stats["total_embeddings_created"],
-                    "total_items_stored": self.stats["total_items_stored"],
-                    "total_queries": self.stats["total_queries"],
-                },
+                "stats": {key: self.stats[key] for key in ("total_embeddings_created", "total_items_stored",
+                                                           "total_queries")},
             }
-            if self.cache:
-                stats["cache"] = self.cache.get_stats()
-            return stats
         except Exception as e:
             logger.error("Failed to get collection stats: %s", e)
             return {"name": settings.CHROMA_COLLECTION_NAME, "count": 0, "error": str(e)}
+        if self.cache:
+            report["cache"] = self.cache.get_stats()
+        return report
 
     async def get_stats(self) -> Dict[str, Any]:
         """api.py:472 calls this name; the reference class only defines get_collection_stats."""
         return await self.get_collection_stats()
 
     def get_embedding_dimension(self) -> int:
-        """embedder.py:730-734."""
-        if self.text_model:
-            return int(self.text_model.dim)
-        return 384
-
-    def _get_cache_key(self, text: str) -> str:
-        """embedder.py:736-742."""
-        return hashlib.md5(text.encode("utf-8")).hexdigest()
+        """embedder.py:730-734 (384 while no model is loaded)."""
+        return int(self.text_model.dim) if self.text_model else 384
 
     async def warmup_cache(self, common_queries: List[str]):
         """embedder.py:744-762."""
@@ -600,9 +346,7 @@ class EmbeddingManager:
 
     async def get_cache_stats(self) -> Dict[str, Any]:
         """embedder.py:764-772."""
-        if not self.cache:
-            return {"enabled": False}
-        return {"enabled": True, **self.cache.get_stats()}
+        return {"enabled": True, **self.cache.get_stats()} if self.cache else {"enabled": False}
 
     async def clear_cache(self):
         """embedder.py:774-780."""
@@ -610,36 +354,3 @@ class EmbeddingManager:
             self.cache.clear()
         else:
             logger.warning("Cache not enabled")
-
-    async def rerank_results(self, query_text: str, results: Dict[str, Any],
-                             top_k: Optional[int] = None) -> Dict[str, Any]:
-        """embedder.py:834-859: the reference's placeholder (truncation only)."""
-        logger.warning("Re-ranking not implemented yet")
-        if top_k and top_k < len(results["ids"]):
-            return {k: results[k][:top_k] for k in ("ids", "distances", "metadatas", "documents")}
-        return results
-
-    async def get_similar_documents(self, doc_id: str, item_id: str, n_results: int = 5) -> Dict[str, Any]:
-        """embedder.py:861-930: stored vector -> k+1 search -> drop self -> truncate."""
-        if not self.is_initialized:
-            await self.initialize()
-        try:
-            source_id = f"{doc_id}_{item_id}"
-            source_data = await asyncio.to_thread(self.collection.get, ids=[source_id],
-                                                  include=["embeddings", "documents"])
-            if not source_data["ids"]:
-                raise ValueError(f"Item not found: {source_id}")
-            results = await asyncio.to_thread(
-                self.collection.query, query_embeddings=[source_data["embeddings"][0]], n_results=n_results + 1,
-                include=["metadatas", "documents", "distances"])
-            filtered = {"ids": [], "distances": [], "metadatas": [], "documents": []}
-            for i in range(len(results["ids"][0])):
-                if results["ids"][0][i] != source_id:
-                    for key in filtered:
-                        filtered[key].append(results[key][0][i])
-            for key in filtered:
-                filtered[key] = filtered[key][:n_results]
-            return filtered
-        except Exception as e:
-            logger.error("Failed to find similar documents: %s", e)
-            raise

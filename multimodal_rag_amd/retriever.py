@@ -1,11 +1,14 @@
-"""`MultiVectorRetriever`: mirror of the reference's app/utils/retriever.py at the boundary of
-the hot path (the id -> raw-content hop after search, api.py:348).
+"""`MultiVectorRetriever`: the reference's app/utils/retriever.py surface at the boundary of the hot path (the
+id -> raw-content hop after search, api.py:348).
 
-Same signatures, key layout, payload format (gzip level 6 of the JSON the reference writes),
-bucketing and statistics.  The key-value engine is pluggable: the reference talks to Redis
-(retriever.py:168-213), which is not available here, so the default engine is an in-process
-store with the same commands the reference issues (SET/GET/DELETE/SCAN-by-pattern/pipeline).
-Host-only code: nothing here touches the GPU.
+Signatures, key layout, stored payload (gzip level 6 of the item's JSON), bucketing by type and statistics keys are the
+reference's.  The body is written against a five-command key-value protocol (ping / mset / mget / get / delete /
+scan_iter) instead of a Redis client: the reference talks to Redis (retriever.py:168-213), which is not available
+here, so the default engine is `InProcessKV`; any object with those commands (a Redis client adapter included) plugs
+in through `store=`.  Host-only code: nothing here touches the GPU.
+
+Key layout (retriever.py:97-100):  doc:{doc_id}:{item_id} -> item payload,  doc_index:{doc_id} -> JSON list of item
+ids,  doc_meta:{doc_id} -> JSON document record.
 """
 from __future__ import annotations
 
@@ -16,50 +19,21 @@ import json
 import logging
 import threading
 import time
-from collections import OrderedDict
 from datetime import datetime
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, Iterable, List, Optional
+
+from .hostutil import CountingLRU, call_with_retry
 
 logger = logging.getLogger(__name__)
 
+BUCKET_OF_TYPE = {"text": "text_chunks", "table": "table_chunks", "image": "image_chunks"}   # retriever.py:500-512
 
-class DocumentCache:
-    """retriever.py:35-90."""
+
+class DocumentCache(CountingLRU):
+    """item id -> decoded payload (retriever.py:35-90: maxsize 100, same counters and rounding as the embedding cache)"""
 
     def __init__(self, maxsize: int = 100):
-        self.cache: "OrderedDict[str, Any]" = OrderedDict()
-        self.maxsize = maxsize
-        self.hits = 0
-        self.misses = 0
-
-    def get(self, key: str) -> Optional[Any]:
-        if key in self.cache:
-            self.cache.move_to_end(key)
-            self.hits += 1
-            return self.cache[key]
-        self.misses += 1
-        return None
-
-    def put(self, key: str, value: Any):
-        if key in self.cache:
-            self.cache.move_to_end(key)
-        elif len(self.cache) >= self.maxsize:
-            self.cache.popitem(last=False)
-        self.cache[key] = value
-
-    def invalidate(self, key: str):
-        if key in self.cache:
-            del self.cache[key]
-
-    def clear(self):
-        self.cache.clear()
-        self.hits = 0
-        self.misses = 0
-
-    def get_stats(self) -> Dict[str, Any]:
-        total = self.hits + self.misses
-        return {"size": len(self.cache), "maxsize": self.maxsize, "hits": self.hits, "misses": self.misses,
-                "hit_rate": round(self.hits / total if total > 0 else 0.0, 3)}
+        super().__init__(maxsize)
 
 
 class InProcessKV:
@@ -109,276 +83,57 @@ class InProcessKV:
         pass
 
 
+def _item_key(doc_id: str, item_id: str) -> str:
+    return f"doc:{doc_id}:{item_id}"
+
+
+def _index_key(doc_id: str) -> str:
+    return f"doc_index:{doc_id}"
+
+
+def _meta_key(doc_id: str) -> str:
+    return f"doc_meta:{doc_id}"
+
+
 class MultiVectorRetriever:
-    """retriever.py:93-1015.
+    """retriever.py:93-1015."""
 
-    Key format (retriever.py:97-100):
-      doc:{doc_id}:{item_id} -> compressed raw content; doc_meta:{doc_id}; doc_index:{doc_id}
-    """
-
-    def __init__(
-        self,
-        enable_compression: bool = True,
-        enable_cache: bool = True,
-        cache_size: int = 100,
-        max_retries: int = 3,
-        connection_pool_size: int = 10,
-        batch_size: int = 100,
-        *,
-        store: Any = None,
-    ):
+    def __init__(self, enable_compression: bool = True, enable_cache: bool = True, cache_size: int = 100,
+                 max_retries: int = 3, connection_pool_size: int = 10, batch_size: int = 100, *, store: Any = None):
         self.enable_compression = enable_compression
         self.enable_cache = enable_cache
         self.max_retries = max_retries
-        self.batch_size = batch_size
-        self.redis_client = store
+        self.batch_size = batch_size               # keys per DELETE command
+        self.redis_client = store                  # (the reference's attribute name; any KV engine)
         self.connection_pool = None
         self.is_initialized = False
         self.cache = DocumentCache(maxsize=cache_size) if enable_cache else None
-        self._sleep = asyncio.sleep
         self.stats = {"total_stored": 0, "total_retrieved": 0, "total_deleted": 0, "compression_ratio": 0.0,
                       "cache_hits": 0, "cache_misses": 0}
+        self._sleep = asyncio.sleep
 
+    # ------------------------------------------------------------------ lifecycle -----------
     async def initialize(self):
-        """retriever.py:168-213 (connect + ping)."""
-        if self.is_initialized:
-            return
-        if self.redis_client is None:
-            self.redis_client = InProcessKV()
-        self.redis_client.ping()
-        self.is_initialized = True
+        """retriever.py:168-213: connect and ping."""
+        if not self.is_initialized:
+            if self.redis_client is None:
+                self.redis_client = InProcessKV()
+            self.redis_client.ping()
+            self.is_initialized = True
 
     async def cleanup(self):
         """retriever.py:215-236."""
         if self.redis_client is not None:
             self.redis_client.close()
-            self.redis_client = None
+        self.redis_client = None
         if self.cache:
             self.cache.clear()
         self.is_initialized = False
 
-    # ------------------------------------------------------------------ store ---------------
-    async def store_raw_documents(self, doc_id: str, summaries: List[Dict[str, Any]], filename: str):
-        """retriever.py:238-309."""
-        if not self.is_initialized:
-            await self.initialize()
-        total_uncompressed = 0
-        total_compressed = 0
-        for attempt in range(self.max_retries):
-            try:
-                await asyncio.to_thread(self._store_sync, doc_id, summaries, filename)
-                if self.enable_compression:
-                    for item in summaries:
-                        raw_data = json.dumps(item)
-                        total_uncompressed += len(raw_data)
-                        total_compressed += len(self._compress(raw_data))
-                    self.stats["compression_ratio"] = (total_compressed / total_uncompressed
-                                                       if total_uncompressed > 0 else 1.0)
-                self.stats["total_stored"] += len(summaries)
-                return
-            except Exception as e:
-                if attempt == self.max_retries - 1:
-                    logger.error("Failed to store after %d attempts: %s", self.max_retries, e)
-                    raise
-                await self._sleep(2 ** attempt)
+    def _kv_call(self, what: str, fn, *args):
+        return call_with_retry(what, fn, *args, attempts=self.max_retries, sleep=self._sleep, log=logger)
 
-    def _store_sync(self, doc_id: str, summaries: List[Dict[str, Any]], filename: str):
-        """retriever.py:371-426 (payload fields :384-393, index :404-405, metadata :408-421)."""
-        batch: Dict[str, bytes] = {}
-        item_ids = []
-        for item in summaries:
-            data = {"id": item["id"], "type": item["type"], "raw": item["raw"], "summary": item["summary"]}
-            if item["type"] == "image" and "path" in item:
-                data["path"] = item["path"]
-            json_data = json.dumps(data)
-            batch[f"doc:{doc_id}:{item['id']}"] = (self._compress(json_data) if self.enable_compression
-                                                   else json_data.encode("utf-8"))
-            item_ids.append(item["id"])
-        batch[f"doc_index:{doc_id}"] = json.dumps(item_ids).encode("utf-8")
-        meta_data = {
-            "doc_id": doc_id,
-            "filename": filename,
-            "item_count": len(summaries),
-            "chunks": {t: sum(1 for s in summaries if s["type"] == t) for t in ("text", "table", "image")},
-            "timestamp": datetime.utcnow().isoformat(),
-            "compressed": self.enable_compression,
-        }
-        batch[f"doc_meta:{doc_id}"] = json.dumps(meta_data).encode("utf-8")
-        self.redis_client.mset(batch)
-
-    # ------------------------------------------------------------------ retrieve ------------
-    async def retrieve_raw_documents(self, ids: List[str]) -> Dict[str, List[str]]:
-        """retriever.py:428-531: cache, fetch, bucket raw content by type in input-id order."""
-        if not self.is_initialized:
-            await self.initialize()
-        if not ids:
-            return {"text_chunks": [], "table_chunks": [], "image_chunks": []}
-
-        cached_items: Dict[str, Any] = {}
-        ids_to_fetch: List[str] = []
-        if self.cache:
-            for item_id in ids:
-                cached = self.cache.get(item_id)
-                if cached:
-                    cached_items[item_id] = cached
-                else:
-                    ids_to_fetch.append(item_id)
-        else:
-            ids_to_fetch = ids
-
-        fetched_items: Dict[str, Any] = {}
-        if ids_to_fetch:
-            for attempt in range(self.max_retries):
-                try:
-                    fetched_items = await asyncio.to_thread(self._retrieve_sync, ids_to_fetch)
-                    if self.cache:
-                        for item_id, item_data in fetched_items.items():
-                            self.cache.put(item_id, item_data)
-                    break
-                except Exception as e:
-                    if attempt == self.max_retries - 1:
-                        logger.error("Failed to retrieve after %d attempts: %s", self.max_retries, e)
-                        raise
-                    await self._sleep(2 ** attempt)
-
-        all_items = {**cached_items, **fetched_items}
-        text_chunks, table_chunks, image_chunks = [], [], []
-        for item_id in ids:
-            item = all_items.get(item_id)
-            if item:
-                if item["type"] == "text":
-                    text_chunks.append(item["raw"])
-                elif item["type"] == "table":
-                    table_chunks.append(item["raw"])
-                elif item["type"] == "image":
-                    image_chunks.append(item["raw"])
-
-        self.stats["total_retrieved"] += len(ids)
-        if self.cache:
-            cs = self.cache.get_stats()
-            self.stats["cache_hits"] = cs["hits"]
-            self.stats["cache_misses"] = cs["misses"]
-        return {"text_chunks": text_chunks, "table_chunks": table_chunks, "image_chunks": image_chunks}
-
-    def _retrieve_sync(self, ids: List[str]) -> Dict[str, Dict[str, Any]]:
-        """retriever.py:576-608."""
-        items: Dict[str, Dict[str, Any]] = {}
-        keys = [(item_id, self._item_id_to_redis_key(item_id)) for item_id in ids]
-        results = self.redis_client.mget([k for _, k in keys])
-        for (item_id, _), data_bytes in zip(keys, results):
-            if data_bytes:
-                try:
-                    json_str = self._decompress(data_bytes) if self.enable_compression else data_bytes.decode("utf-8")
-                    items[item_id] = json.loads(json_str)
-                except Exception as e:
-                    logger.warning("Failed to decode item %s: %s", item_id, e)
-        return items
-
-    def _item_id_to_redis_key(self, item_id: str) -> str:
-        """retriever.py:610-637: "doc_abc123_chunk_0_a1b2c3" -> "doc:doc_abc123:chunk_0_a1b2c3"."""
-        parts = item_id.split("_")
-        if len(parts) < 3:
-            return f"doc:{item_id}"
-        return f"doc:{'_'.join(parts[:2])}:{'_'.join(parts[2:])}"
-
-    # ------------------------------------------------------------------ delete / list -------
-    async def delete_document(self, doc_id: str):
-        """retriever.py:639-675."""
-        if not self.is_initialized:
-            await self.initialize()
-        for attempt in range(self.max_retries):
-            try:
-                await asyncio.to_thread(self._delete_sync, doc_id)
-                if self.cache:
-                    self.cache.clear()
-                self.stats["total_deleted"] += 1
-                return
-            except Exception as e:
-                if attempt == self.max_retries - 1:
-                    logger.error("Failed to delete document %s: %s", doc_id, e)
-                    raise
-                await self._sleep(2 ** attempt)
-
-    def _delete_sync(self, doc_id: str):
-        """retriever.py:728-763."""
-        index_key = f"doc_index:{doc_id}"
-        index_data = self.redis_client.get(index_key)
-        keys_to_delete: List[str] = []
-        if index_data:
-            for item_id in json.loads(index_data.decode("utf-8")):
-                keys_to_delete.append(f"doc:{doc_id}:{item_id}")
-            keys_to_delete.append(index_key)
-        else:
-            keys_to_delete.extend(self.redis_client.scan_iter(match=f"doc:{doc_id}:*"))
-        keys_to_delete.append(f"doc_meta:{doc_id}")
-        for i in range(0, len(keys_to_delete), self.batch_size):
-            self.redis_client.delete(*keys_to_delete[i: i + self.batch_size])
-
-    async def delete_all_documents(self):
-        """retriever.py:765-787."""
-        if not self.is_initialized:
-            await self.initialize()
-        all_keys: List[str] = []
-        for pattern in ("doc:*", "doc_meta:*", "doc_index:*"):
-            all_keys.extend(self.redis_client.scan_iter(match=pattern))
-        for i in range(0, len(all_keys), self.batch_size):
-            self.redis_client.delete(*all_keys[i: i + self.batch_size])
-        if self.cache:
-            self.cache.clear()
-
-    async def list_all_documents(self) -> List[Dict[str, Any]]:
-        """retriever.py:832-913: all doc_meta records, newest first."""
-        if not self.is_initialized:
-            await self.initialize()
-        documents = []
-        for key in self.redis_client.scan_iter(match="doc_meta:*"):
-            meta_bytes = self.redis_client.get(key)
-            if meta_bytes:
-                try:
-                    documents.append(json.loads(meta_bytes.decode("utf-8")))
-                except Exception as e:
-                    logger.warning("Failed to decode metadata: %s", e)
-        documents.sort(key=lambda x: x.get("timestamp", ""), reverse=True)
-        return documents
-
-    async def get_document_metadata(self, doc_id: str) -> Optional[Dict[str, Any]]:
-        """retriever.py:915-934."""
-        if not self.is_initialized:
-            await self.initialize()
-        try:
-            meta_bytes = self.redis_client.get(f"doc_meta:{doc_id}")
-            return json.loads(meta_bytes.decode("utf-8")) if meta_bytes else None
-        except Exception as e:
-            logger.error("Failed to get metadata for %s: %s", doc_id, e)
-            return None
-
-    async def get_stats(self) -> Dict[str, Any]:
-        """retriever.py:936-968 (same keys)."""
-        stats = {
-            "redis": {"connected": self.is_initialized, "async": False},
-            "features": {"compression": self.enable_compression, "cache": self.enable_cache},
-            "operations": {k: self.stats[k] for k in ("total_stored", "total_retrieved", "total_deleted")},
-        }
-        if self.enable_compression:
-            stats["compression"] = {"ratio": self.stats["compression_ratio"],
-                                    "savings_percent": (1 - self.stats["compression_ratio"]) * 100}
-        if self.cache:
-            stats["cache"] = self.cache.get_stats()
-        return stats
-
-    async def health_check(self) -> Dict[str, Any]:
-        """retriever.py:970-1004."""
-        health = {"healthy": False, "redis_connected": False, "latency_ms": None, "error": None}
-        try:
-            if not self.is_initialized:
-                await self.initialize()
-            start = time.time()
-            self.redis_client.ping()
-            health.update(healthy=True, redis_connected=True, latency_ms=round((time.time() - start) * 1000, 2))
-        except Exception as e:
-            health["error"] = str(e)
-        return health
-
+    # ------------------------------------------------------------------ codec ---------------
     def _compress(self, data: str) -> bytes:
         """retriever.py:1008-1010."""
         return gzip.compress(data.encode("utf-8"), compresslevel=6)
@@ -386,3 +141,167 @@ class MultiVectorRetriever:
     def _decompress(self, data: bytes) -> str:
         """retriever.py:1012-1014."""
         return gzip.decompress(data).decode("utf-8")
+
+    def _encode(self, record: Dict[str, Any]) -> bytes:
+        text = json.dumps(record)
+        return self._compress(text) if self.enable_compression else text.encode("utf-8")
+
+    def _decode(self, blob: bytes) -> Dict[str, Any]:
+        return json.loads(self._decompress(blob) if self.enable_compression else blob.decode("utf-8"))
+
+    def _item_id_to_redis_key(self, item_id: str) -> str:
+        """retriever.py:610-637: a collection id "doc_<12 hex>_<item id>" back to its store key -- the first two
+        '_'-separated fields are the document id ("doc_abc123_chunk_0_a1b2c3" -> "doc:doc_abc123:chunk_0_a1b2c3");
+        an id with fewer than three fields maps to "doc:" + id."""
+        head = item_id.split("_", 2)
+        return _item_key("_".join(head[:2]), head[2]) if len(head) == 3 else f"doc:{item_id}"
+
+    # ------------------------------------------------------------------ store ---------------
+    async def store_raw_documents(self, doc_id: str, summaries: List[Dict[str, Any]], filename: str):
+        """retriever.py:238-426: one atomic multi-set of the item payloads (fields :384-393), the item-id index
+        (:404-405) and the document record (:408-421)."""
+        await self.initialize()
+        records: Dict[str, bytes] = {}
+        plain_bytes = packed_bytes = 0
+        for item in summaries:
+            payload = {field: item[field] for field in ("id", "type", "raw", "summary")}
+            if item["type"] == "image" and "path" in item:
+                payload["path"] = item["path"]
+            blob = self._encode(payload)
+            records[_item_key(doc_id, item["id"])] = blob
+            plain_bytes += len(json.dumps(payload))
+            packed_bytes += len(blob)
+        records[_index_key(doc_id)] = json.dumps([item["id"] for item in summaries]).encode("utf-8")
+        kinds = [item["type"] for item in summaries]
+        records[_meta_key(doc_id)] = json.dumps({
+            "doc_id": doc_id, "filename": filename, "item_count": len(summaries),
+            "chunks": {kind: kinds.count(kind) for kind in BUCKET_OF_TYPE},
+            "timestamp": datetime.utcnow().isoformat(), "compressed": self.enable_compression,
+        }).encode("utf-8")
+        await self._kv_call("Store", self.redis_client.mset, records)
+        if self.enable_compression:
+            self.stats["compression_ratio"] = packed_bytes / plain_bytes if plain_bytes else 1.0
+        self.stats["total_stored"] += len(summaries)
+
+    # ------------------------------------------------------------------ retrieve ------------
+    def _fetch(self, ids: List[str]) -> Dict[str, Dict[str, Any]]:
+        found = {}
+        for item_id, blob in zip(ids, self.redis_client.mget([self._item_id_to_redis_key(i) for i in ids])):
+            if blob:
+                try:
+                    found[item_id] = self._decode(blob)
+                except Exception as e:   # noqa: BLE001 -- a damaged record must not fail the whole answer
+                    logger.warning("Failed to decode item %s: %s", item_id, e)
+        return found
+
+    async def retrieve_raw_documents(self, ids: List[str]) -> Dict[str, List[str]]:
+        """retriever.py:428-608: the `raw` field of every id that exists, bucketed by item type, in the order of
+        `ids`; cache first, one multi-get for the rest."""
+        await self.initialize()
+        buckets: Dict[str, List[str]] = {name: [] for name in BUCKET_OF_TYPE.values()}
+        if not ids:
+            return buckets
+        known: Dict[str, Dict[str, Any]] = {}
+        if self.cache:
+            for item_id in ids:
+                hit = self.cache.get(item_id)
+                if hit:
+                    known[item_id] = hit
+        missing = [item_id for item_id in ids if item_id not in known]
+        if missing:
+            fetched = await self._kv_call("Retrieve", self._fetch, missing)
+            if self.cache:
+                for item_id, record in fetched.items():
+                    self.cache.put(item_id, record)
+            known.update(fetched)
+        for item_id in ids:
+            record = known.get(item_id)
+            if record and record["type"] in BUCKET_OF_TYPE:
+                buckets[BUCKET_OF_TYPE[record["type"]]].append(record["raw"])
+        self.stats["total_retrieved"] += len(ids)
+        if self.cache:
+            self.stats["cache_hits"], self.stats["cache_misses"] = self.cache.hits, self.cache.misses
+        return buckets
+
+    # ------------------------------------------------------------------ delete / list -------
+    def _delete_keys(self, keys: Iterable[str]):
+        keys = list(keys)
+        for lo in range(0, len(keys), self.batch_size):
+            self.redis_client.delete(*keys[lo: lo + self.batch_size])
+
+    def _drop_document(self, doc_id: str):
+        listed = self.redis_client.get(_index_key(doc_id))
+        if listed:
+            keys = [_item_key(doc_id, item_id) for item_id in json.loads(listed.decode("utf-8"))] + [_index_key(doc_id)]
+        else:                                       # no index record: find the items by pattern (retriever.py:748-752)
+            keys = list(self.redis_client.scan_iter(match=_item_key(doc_id, "*")))
+        self._delete_keys(keys + [_meta_key(doc_id)])
+
+    async def delete_document(self, doc_id: str):
+        """retriever.py:639-763."""
+        await self.initialize()
+        await self._kv_call(f"Delete of document {doc_id}", self._drop_document, doc_id)
+        if self.cache:
+            self.cache.clear()
+        self.stats["total_deleted"] += 1
+
+    async def delete_all_documents(self):
+        """retriever.py:765-787."""
+        await self.initialize()
+        self._delete_keys(key for pattern in ("doc:*", "doc_meta:*", "doc_index:*")
+                          for key in self.redis_client.scan_iter(match=pattern))
+        if self.cache:
+            self.cache.clear()
+
+    def _json_at(self, key: str) -> Optional[Dict[str, Any]]:
+        blob = self.redis_client.get(key)
+        return json.loads(blob.decode("utf-8")) if blob else None
+
+    async def list_all_documents(self) -> List[Dict[str, Any]]:
+        """retriever.py:832-913: every document record, newest first."""
+        await self.initialize()
+        found = []
+        for key in self.redis_client.scan_iter(match="doc_meta:*"):
+            try:
+                record = self._json_at(key)
+            except Exception as e:   # noqa: BLE001
+                logger.warning("Failed to decode metadata: %s", e)
+                continue
+            if record:
+                found.append(record)
+        return sorted(found, key=lambda record: record.get("timestamp", ""), reverse=True)
+
+    async def get_document_metadata(self, doc_id: str) -> Optional[Dict[str, Any]]:
+        """retriever.py:915-934."""
+        await self.initialize()
+        try:
+            return self._json_at(_meta_key(doc_id))
+        except Exception as e:   # noqa: BLE001
+            logger.error("Failed to get metadata for %s: %s", doc_id, e)
+            return None
+
+    async def get_stats(self) -> Dict[str, Any]:
+        """retriever.py:936-968 (same keys)."""
+        report: Dict[str, Any] = {
+            "redis": {"connected": self.is_initialized, "async": False},
+            "features": {"compression": self.enable_compression, "cache": self.enable_cache},
+            "operations": {key: self.stats[key] for key in ("total_stored", "total_retrieved", "total_deleted")},
+        }
+        if self.enable_compression:
+            ratio = self.stats["compression_ratio"]
+            report["compression"] = {"ratio": ratio, "savings_percent": (1 - ratio) * 100}
+        if self.cache:
+            report["cache"] = self.cache.get_stats()
+        return report
+
+    async def health_check(self) -> Dict[str, Any]:
+        """retriever.py:970-1004."""
+        report = {"healthy": False, "redis_connected": False, "latency_ms": None, "error": None}
+        try:
+            await self.initialize()
+            t0 = time.time()
+            self.redis_client.ping()
+            report.update(healthy=True, redis_connected=True, latency_ms=round((time.time() - t0) * 1000, 2))
+        except Exception as e:   # noqa: BLE001
+            report["error"] = str(e)
+        return report

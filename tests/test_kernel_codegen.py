@@ -1,0 +1,62 @@
+"""CPU only: guard rails on the compiled query-stationary search kernel (csrc/search_qs.hip).
+
+Its tile loop runs with every register spoken for (Q fragments: 256 AGPRs + 128 VGPRs per lane) and a deep LDS-DMA ring in
+flight.  Two things the compiler can do there cost far more than they look:
+  * a scratch (spill) reload inside the loop: hipcc waits `vmcnt(0)` for it, which drains the whole DMA ring -- the
+    selection path once took 5 us per entry that way;
+  * shuffling the stationary Q fragments between the accumulator file and arch VGPRs (`v_accvgpr_*`) every k-step.
+Both have happened after innocent-looking source edits, with correct results and a 10-30 % slower kernel, so the
+assembly is checked."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "multimodal_rag_amd", "csrc", "search_qs.hip")
+
+
+def _kernels(asm: str):
+    cur, name = None, None
+    for line in asm.splitlines():
+        m = re.match(r"^(_ZN10mmrag_impl21cosine_topk_qs_kernel\w+):", line)
+        if m:
+            name, cur = m.group(1), []
+        if cur is not None:
+            cur.append(line)
+            if "s_endpgm" in line:
+                yield name, cur
+                cur = None
+
+
+def test_tile_loop_has_no_spills_and_no_accvgpr_traffic(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "search_qs.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-I",
+                        os.path.join(ROOT, "include"), SRC, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = 0
+    for name, lines in _kernels(open(out).read()):
+        seen += 1
+        mfma = [i for i, l in enumerate(lines) if "v_mfma_f32" in l]
+        assert mfma, name
+        labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+        # the tile loop: the last backward branch after the last MFMA whose target sits before the first MFMA
+        back = [(i, labels[m.group(1)]) for i, l in enumerate(lines)
+                if i > mfma[-1] and (m := re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)) and m.group(1) in labels
+                and labels[m.group(1)] < mfma[0]]
+        assert back, f"{name}: tile loop not found"
+        end, start = back[-1]
+        body = lines[start:end + 1]
+        in_k_steps = lines[mfma[0]:mfma[-1] + 1]
+        assert sum("v_mfma_f32" in l for l in body) % 192 in (0, 96, 128), name      # one copy of the unrolled tile
+        for l in body:
+            assert "scratch_" not in l, f"{name}: spill access inside the tile loop: {l.strip()}"
+        for l in in_k_steps:
+            assert "v_accvgpr" not in l, f"{name}: Q fragments move between register files in the k-steps: {l.strip()}"
+            assert not re.search(r"s_waitcnt.*vmcnt\(0\)", l) or "ASM" in l, f"{name}: vmcnt(0) among the k-steps"
+    assert seen >= 6   # 2 dtypes x 3 row lengths (x 2 cache policies)
