@@ -145,7 +145,7 @@ def padded_dim(d: int, dtype: torch.dtype) -> int:
 
 
 # kernel-shape switches of the debug entry point (tests / A-B tools; the product always passes 0)
-DBG_NO_PREPASS, DBG_8_WAVES, DBG_NO_QS = 1, 2, 4
+DBG_NO_PREPASS, DBG_8_WAVES, DBG_NO_QS, DBG_FORCE_QS = 1, 2, 4, 8
 
 
 def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, row_offset: int = 0,

@@ -43,6 +43,10 @@ class Settings:
     MMRAG_MODEL_DIR: str = field(default_factory=lambda: os.getenv("MMRAG_MODEL_DIR", ""))
     MMRAG_INDEX_DTYPE: str = field(default_factory=lambda: os.getenv("MMRAG_INDEX_DTYPE", "float16"))
     MMRAG_WEIGHT_SEED: int = field(default_factory=lambda: int(os.getenv("MMRAG_WEIGHT_SEED", "0")))
+    # keep the collection across restarts: load it from CHROMA_PERSIST_DIR/mmrag_index in initialize(), save it there in
+    # cleanup().  Off by default, as in the reference's current code: its chromadb.Client(Settings(persist_directory=...))
+    # lacks is_persistent=True, i.e. the reference's collection is in-memory too
+    MMRAG_PERSIST: bool = field(default_factory=lambda: _b("MMRAG_PERSIST", "false"))
     # CLIP engines only: embed image items from their pixels (vision tower) instead of their summary text
     MMRAG_EMBED_IMAGE_PIXELS: bool = field(default_factory=lambda: _b("MMRAG_EMBED_IMAGE_PIXELS", "true"))
 

@@ -5,6 +5,8 @@
 #include <hip/hip_bf16.h>
 #include <string.h>
 
+#include <atomic>
+
 namespace mmrag {
 
 static thread_local char g_err[512] = "";
@@ -15,6 +17,10 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// developer switches for A/B runs (mmrag_internal_set_debug; never set by the product): one relaxed word, no getenv
+static std::atomic<unsigned> g_debug{0};
+unsigned debug_flags() { return g_debug.load(std::memory_order_relaxed); }
 
 int num_cus() {
     static int cached[16] = {0};
@@ -97,6 +103,9 @@ using namespace mmrag_impl;
 extern "C" {
 
 int mmrag_abi_version(void) { return 1; }
+
+// A/B switches of the encoder GEMM (tools/linear_vs_rocblas.py); exported for the tools, absent from include/mmrag.h
+void mmrag_internal_set_debug(unsigned flags) { mmrag::g_debug.store(flags, std::memory_order_relaxed); }
 
 const char *mmrag_last_error(void) { return mmrag::g_err; }
 

@@ -178,6 +178,7 @@ struct LinearParams {
     int M, N, K;
     int act;
     int xcd_order;
+    unsigned dbg;
 };
 
 template <int BF, int BT, int WF, int WT, int NSTAGE, bool PIPE = false>
@@ -852,8 +853,10 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
     p.resid = (const _Float16 *)resid;
     p.out = (_Float16 *)out;
     p.M = M, p.N = N, p.K = K, p.act = act;
-    p.xcd_order = getenv("MMRAG_LINEAR_PLAIN") ? 0 : 1;
-    if (M <= 64 && (K / 4) % 16 == 0 && !getenv("MMRAG_LINEAR_NO_SMALL")) {
+    const unsigned dbg = debug_flags();
+    p.xcd_order = (dbg & DBG_LINEAR_PLAIN) ? 0 : 1;
+    p.dbg = dbg;
+    if (M <= 64 && (K / 4) % 16 == 0 && !(dbg & DBG_LINEAR_NO_SMALL)) {
         // the online single-query path: split-K over the 16 / 8 / 4 waves of a 32-feature workgroup
         const unsigned g = (unsigned)((N + 31) / 32);
         if (K % 256 == 0) linear_small_kernel<16><<<g, 1024, 0, s>>>(p);
@@ -871,7 +874,7 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
         // 16 waves (4 per SIMD): +10-20 % over 8 waves on the encoder shapes (A/B in one process)
         // 16 waves (4 per SIMD): +10-20 % over 8 waves on the encoder shapes; software-pipelined fragment
         // reads + XCD-aware tile order: another +4-15 % (A/B in one process, tools/linear_vs_rocblas.py)
-        if (getenv("MMRAG_LINEAR_PLAIN"))
+        if (dbg & DBG_LINEAR_PLAIN)
             linear_kernel<256, 256, 4, 4, 2><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
         else
             linear_kernel<256, 256, 4, 4, 2, true><<<(unsigned)big_tiles, 1024, 0, s>>>(p);

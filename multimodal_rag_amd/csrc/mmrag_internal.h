@@ -33,4 +33,8 @@ inline int esize(int dtype) { return dtype == MMRAG_F32 ? 4 : 2; }
 // number of CUs of the current device (cached per device id)
 int num_cus();
 
+// developer switches (set through mmrag_internal_set_debug by A/B tools only)
+unsigned debug_flags();
+constexpr unsigned DBG_LINEAR_PLAIN = 1u, DBG_LINEAR_NO_SMALL = 2u;
+
 }  // namespace mmrag

@@ -478,11 +478,12 @@ struct Plan {
     int n_lists;
     int b_pad;
     int pre_tiles;  // > 0: a sample pre-pass over the first pre_tiles tiles seeds the selection thresholds
-    bool qs_ok;     // shape admits the query-stationary kernel (search_qs.hip) when dtype / row length do
+    bool qs_ok;     // shape goes to the query-stationary kernel (search_qs.hip) when dtype / row length allow
+    bool qs_room;   // ... could go there (debug switch DBG_FORCE_QS): the workspace keeps room for its sample pass
 };
 
 // debug switches of mmrag_internal_cosine_topk_lists_ex (tests and A/B tools only; never set by the product)
-constexpr unsigned DBG_NO_PREPASS = 1u, DBG_8_WAVES = 2u, DBG_NO_QS = 4u;
+constexpr unsigned DBG_NO_PREPASS = 1u, DBG_8_WAVES = 2u, DBG_NO_QS = 4u, DBG_FORCE_QS = 8u;
 
 // n_lists, b_pad and pre_tiles depend on (B, n, k) only: mmrag_cosine_topk_select and the workspace query
 // have no dtype, so both kernels keep the same list layout
@@ -511,9 +512,11 @@ Plan make_plan(int B, long long n, int k, unsigned dbg = 0) {
     if (want_pre && !(dbg & DBG_NO_PREPASS)) pl.pre_tiles = cus;
     pl.n_lists = pl.grid_x + (want_pre ? 1 : 0);  // one merged list per workgroup per query (+ the sample's)
     pl.b_pad = pl.grid_y * qrows;
-    // query-stationary kernel: more than 128 queries, and a shard big enough that every walker of the
-    // slab-ring plan (same grid, same list slots) gets 64-row tiles of its own
-    pl.qs_ok = pl.WN == 8 && pl.n_tiles >= cus && !(dbg & DBG_NO_QS);
+    // query-stationary kernel: more than 128 queries and a long shard.  It needs >= 256 rows per walker to run at
+    // all (qs_room); it pays from about 6 tiles of 256 rows per CU (profiles/r02_config_sweep.txt: 1M rows 424 vs
+    // 463 us, 500k 248 vs 258, 250k 164 vs 159, 125k 178 vs 99 -- its launches have ~35 us of fixed cost each).
+    pl.qs_room = pl.WN == 8 && pl.n_tiles >= cus;
+    pl.qs_ok = pl.qs_room && !(dbg & DBG_NO_QS) && (pl.n_tiles >= 6 * cus || (dbg & DBG_FORCE_QS));
     return pl;
 }
 
@@ -606,7 +609,7 @@ static WsLayout ws_layout(const Plan &pl) {
     w.off_cnt = (w.off_tr + (size_t)pl.b_pad * pl.K * sizeof(long long) + 63) / 64 * 64;
     w.cnt_bytes = 0;
     w.off_pub = w.off_cnt + w.cnt_bytes;
-    w.total = w.off_pub + (pl.qs_ok ? (size_t)pl.b_pad * pl.grid_x * sizeof(float) : 0);
+    w.total = w.off_pub + (pl.qs_room ? (size_t)pl.b_pad * pl.grid_x * sizeof(float) : 0);
     return w;
 }
 

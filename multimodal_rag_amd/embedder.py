@@ -81,6 +81,8 @@ class EmbeddingManager:
             self.text_model = self.client = self._engine
             self.device = getattr(self._engine, "device_name", self.device or "cuda")
             self.collection = self._engine.new_collection(settings.CHROMA_COLLECTION_NAME, dict(_COLLECTION_NOTE))
+            if settings.MMRAG_PERSIST:
+                self._restore_collection()
             self.is_initialized = True
             logger.info("EmbeddingManager initialized (device=%s, dim=%d)", self.device, self.get_embedding_dimension())
         except Exception as e:
@@ -91,8 +93,45 @@ class EmbeddingManager:
         if not self.is_initialized:
             await self.initialize()
 
+    def _persist_dir(self) -> str:
+        import os
+
+        return os.path.join(settings.CHROMA_PERSIST_DIR, "mmrag_index")
+
+    def _restore_collection(self):
+        """MMRAG_PERSIST: pick up what the last cleanup() saved (a collection with load(), or a VectorIndex directory)"""
+        import os
+
+        where = self._persist_dir()
+        if not os.path.isdir(where):
+            return
+        if hasattr(self.collection, "load"):                 # serving.ShardedCollection
+            self.collection.load(where)
+        elif os.path.exists(os.path.join(where, "tables.json")):
+            from .persistence import load_index
+
+            self.collection = load_index(where, device=str(getattr(self.collection, "device", "cuda:0")))
+        logger.info("Restored %d rows from %s", self.collection.count(), where)
+
+    def _save_collection(self):
+        import os
+
+        where = self._persist_dir()
+        os.makedirs(where, exist_ok=True)
+        if hasattr(self.collection, "save"):
+            self.collection.save(where)
+        elif hasattr(self.collection, "matrix"):
+            from .persistence import save_index
+
+            save_index(self.collection, where)
+
     async def cleanup(self):
         """embedder.py:250-264."""
+        if settings.MMRAG_PERSIST and self.collection is not None:
+            try:
+                await asyncio.to_thread(self._save_collection)
+            except Exception as e:   # noqa: BLE001 -- shutting down: report, do not mask the shutdown
+                logger.error("Could not save the collection: %s", e)
         if self._dispatcher is not None:
             await self._dispatcher.stop()
             self._dispatcher = None

@@ -98,3 +98,41 @@ def test_wal_replay_into_gpu_index(tmp_path, wal70):
     assert sorted(idx.get()["ids"]) == sorted(ref.ids) and idx.count() == ref.count() > 0
     q = wal70["vectors"][:5]
     assert idx.query(q, n_results=3)["ids"] == ref.query(q, n_results=3)["ids"]
+
+
+@pytest.mark.gpu
+def test_manager_persists_across_restarts_when_asked(tmp_path, monkeypatch):
+    """MMRAG_PERSIST=true: cleanup() saves the collection under CHROMA_PERSIST_DIR, the next initialize() restores it"""
+    import asyncio
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodal_rag_amd.config import settings
+    from multimodal_rag_amd.embedder import EmbeddingManager, HipEngine
+
+    monkeypatch.setattr(settings, "MMRAG_PERSIST", True)
+    monkeypatch.setattr(settings, "CHROMA_PERSIST_DIR", str(tmp_path))
+    items = [{"id": f"text_{i}", "summary": f"persisted passage {i}", "raw": "", "type": "text"} for i in range(40)]
+
+    async def first():
+        m = EmbeddingManager(engine=HipEngine("sentence-transformers/all-MiniLM-L6-v2"))
+        await m.embed_and_store(items, "doc_aaaaaaaaaaaa")
+        await m.delete_document("doc_nothing")
+        r = await m.query("persisted passage 7", n_results=3)
+        await m.cleanup()
+        return r
+
+    async def second():
+        m = EmbeddingManager(engine=HipEngine("sentence-transformers/all-MiniLM-L6-v2"))
+        await m.initialize()
+        n = (await m.get_collection_stats())["count"]
+        r = await m.query("persisted passage 7", n_results=3)
+        return n, r
+
+    r1 = asyncio.run(first())
+    n, r2 = asyncio.run(second())
+    import numpy as np
+
+    assert n == 40 and r1["ids"] == r2["ids"] and np.allclose(r1["distances"], r2["distances"], atol=1e-5)

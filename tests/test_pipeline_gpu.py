@@ -265,7 +265,7 @@ def test_tombstone_deletes_interleaved_with_adds_and_queries(gpu):
     d = 768
     idx = VectorIndex(d, dtype=torch.float16, capacity=1024)
     g = np.random.default_rng(5)
-    n = 70_000                                # big enough for the query-stationary kernel at B = 160
+    n = 70_000
     V = unit(n, d, 3)
     V[40_000] = V[11]                         # an exact tie across the delete boundary
     ids = [f"doc_{i // 1000:012x}_text_{i % 1000}" for i in range(n)]

@@ -231,9 +231,9 @@ def test_randomised_shapes_against_oracle(N):
             raise AssertionError(f"trial {trial}: B={B} n={n} d={d} k={k} {dtype} mask={mode} off={off}") from e
 
 
-# ---- query-stationary kernel (csrc/search_qs.hip): more than 128 queries, shards of >= 256 rows per CU, fp16/bf16
-# rows of 768 / 1024 / 1536 bytes.  Every case below is also run through the slab-ring kernel (dbg=DBG_NO_QS) and
-# the two must agree bit for bit.
+# ---- query-stationary kernel (csrc/search_qs.hip): more than 128 queries, fp16/bf16 rows of 768 / 1024 / 1536 bytes.
+# The product sends shards of >= 6 x 256 rows per CU there; DBG_FORCE_QS makes it take the small shards of these tests
+# (>= 256 rows per CU).  Every case is also run through the slab-ring kernel (DBG_NO_QS): bit-for-bit agreement.
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,d", [
     (129, 70_000, 768), (256, 66_000, 768), (200, 65_537, 512), (256, 70_001, 384), (300, 131_123, 768),
@@ -242,11 +242,11 @@ def test_randomised_shapes_against_oracle(N):
 def test_query_stationary_parity(N, dtype, B, n, d):
     q = unit_rows(B, d, 31)
     c = unit_rows(n, d, 32)
-    s, r, es, er = run(N, q, c, 5, dtype)
+    s, r, es, er = run(N, q, c, 5, dtype, dbg=N.DBG_FORCE_QS)
     check(s, r, es, er)
     qd, _ = to_dev(N, q, dtype)
     cd, _ = to_dev(N, c, dtype)
-    for dbg in (N.DBG_NO_QS, N.DBG_NO_PREPASS, N.DBG_NO_QS | N.DBG_NO_PREPASS):
+    for dbg in (N.DBG_NO_QS, N.DBG_FORCE_QS | N.DBG_NO_PREPASS, N.DBG_NO_QS | N.DBG_NO_PREPASS, 0):
         s2, r2 = N.cosine_topk(qd, cd, n, d, 5, dbg=dbg)
         assert np.array_equal(r2.cpu().numpy(), r) and np.array_equal(s2.cpu().numpy(), s), dbg
 
@@ -258,10 +258,10 @@ def test_query_stationary_exact_integers_and_ties(N):
     c = g.integers(-2, 3, size=(n, d)).astype(np.float32)
     q = g.integers(-2, 3, size=(B, d)).astype(np.float32)
     for k in (1, 5):
-        s, r, es, er = run(N, q, c, k, torch.float16)
+        s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_FORCE_QS)
         assert np.array_equal(s, es)
         assert np.array_equal(r, er)
-        s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_NO_PREPASS)   # no in-kernel seeding
+        s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_FORCE_QS | N.DBG_NO_PREPASS)   # no sample pass
         assert np.array_equal(s, es)
         assert np.array_equal(r, er)
 
@@ -273,11 +273,11 @@ def test_query_stationary_masks_offsets_ragged(N):
     c = unit_rows(n, d, 42)
     g = np.random.default_rng(43)
     alive = g.random(n) < 0.5
-    for dbg in (0, N.DBG_NO_PREPASS):
+    for dbg in (N.DBG_FORCE_QS, N.DBG_FORCE_QS | N.DBG_NO_PREPASS):
         check(*run(N, q, c, 5, torch.float16, row_offset=1_000_000, alive=alive, dbg=dbg))
     few = np.zeros(n, dtype=bool)
     few[[5, 40_000, n - 1]] = True            # 3 live rows < k
     none = np.zeros(n, dtype=bool)
-    for dbg in (0, N.DBG_NO_PREPASS):
+    for dbg in (N.DBG_FORCE_QS, N.DBG_FORCE_QS | N.DBG_NO_PREPASS):
         check(*run(N, q, c, 5, torch.float16, alive=few, dbg=dbg))
         check(*run(N, q, c, 5, torch.float16, alive=none, dbg=dbg))
