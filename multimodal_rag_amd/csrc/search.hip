@@ -182,7 +182,38 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cosine_topk_kernel(const KPar
         }
         const char *st = smem + (it % NSTAGE) * STAGE;
 
-        if constexpr (DT == MMRAG_F32) {
+        if constexpr (DT == MMRAG_F32 && WN >= 4) {
+            // fp32 storage, more than 64 queries (BASELINE config 2 at B = 256): the exact f32 MFMA runs at 1/16 of
+            // the bf16 rate and this shape is matrix-bound, so every operand fragment is split on the fly into two
+            // bf16 terms (x = hi + lo up to 2^-17 |x|) and the product is taken as hi*hi + hi*lo + lo*hi in fp32
+            // accumulators: |score error| <= 3 * 2^-17 * sum|q_i c_i| + 2^-16 <= 4e-5 for unit vectors, inside the
+            // 1e-4 parity bound (tests/test_search_gpu.py::test_fp32_split_*), at 3/16 of the f32-MFMA cost.
+            // Batches of <= 64 queries are HBM- / launch-bound and keep the exact f32 MFMA below.
+            auto split = [&](const char *at0, const char *at1, bf16x8_t &hi, bf16x8_t &lo) {
+                const f32x4_t x0 = *(const f32x4_t *)at0, x1 = *(const f32x4_t *)at1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float x = i < 4 ? x0[i] : x1[i - 4];
+                    const __bf16 hb = (__bf16)x;
+                    hi[i] = hb;
+                    lo[i] = (__bf16)(x - (float)hb);
+                }
+            };
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {          // two 16-deep bf16 k-steps per 128-byte fp32 slab
+                const int o0 = ((4 * s2 + 2 * h) ^ sw) * 16, o1 = ((4 * s2 + 2 * h + 1) ^ sw) * 16;
+                bf16x8_t qh, ql;
+                split(st + b_base + o0, st + b_base + o1, qh, ql);
+#pragma unroll
+                for (int b = 0; b < RM; ++b) {
+                    bf16x8_t ch, cl;
+                    split(st + a_base + b * (32 * SLAB) + o0, st + a_base + b * (32 * SLAB) + o1, ch, cl);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl, qh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, ql, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, qh, acc[b], 0, 0, 0);
+                }
+            }
+        } else if constexpr (DT == MMRAG_F32) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int off = ((2 * m + h) ^ sw) * 16;

@@ -281,3 +281,29 @@ def test_query_stationary_masks_offsets_ragged(N):
     for dbg in (N.DBG_FORCE_QS, N.DBG_FORCE_QS | N.DBG_NO_PREPASS):
         check(*run(N, q, c, 5, torch.float16, alive=few, dbg=dbg))
         check(*run(N, q, c, 5, torch.float16, alive=none, dbg=dbg))
+
+
+# ---- fp32 storage, more than 64 queries: scores come from a 3-term bf16 split (csrc/search.hip); the bound is the
+# north star's 1e-4, tested on the reference's own vectors and on random data; integer data stays bit-exact
+def test_fp32_split_on_the_wal70_vectors(N, wal70):
+    V = wal70["vectors"]
+    g = np.random.default_rng(3)
+    q = np.concatenate([V, V[g.integers(0, 70, 130)] + 0.05 * unit_rows(130, V.shape[1], 8)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    s, r, es, er = run(N, q.astype(np.float32), V, 5, torch.float32)          # B = 200 -> split path
+    assert np.abs(s - es).max() <= 1e-4 and O.same_topk_sets(r, s, er, es)
+    assert np.array_equal(r[:70, 0], np.arange(70))                            # every stored vector finds itself first
+    s1, r1, _, _ = run(N, q[:60].astype(np.float32), V, 5, torch.float32)      # B = 60 -> exact f32 MFMA
+    assert np.abs(s1 - s[:60]).max() <= 5e-5
+
+
+@pytest.mark.parametrize("B,n,d", [(256, 100_000, 384), (200, 30_000, 768), (300, 70_001, 100)])
+def test_fp32_split_random_and_exact_integers(N, B, n, d):
+    q, c = unit_rows(B, d, 51), unit_rows(n, d, 52)
+    s, r, es, er = run(N, q, c, 5, torch.float32)
+    assert np.abs(s - es).max() <= 1e-4 and O.same_topk_sets(r, s, er, es)
+    g = np.random.default_rng(53)
+    ci = g.integers(-3, 4, size=(n, d)).astype(np.float32)
+    qi = g.integers(-3, 4, size=(B, d)).astype(np.float32)
+    s, r, es, er = run(N, qi, ci, 5, torch.float32)
+    assert np.array_equal(s, es) and np.array_equal(r, er)                     # small integers: hi term exact, lo = 0
