@@ -224,6 +224,13 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
     static_assert(PPS == 6 || PPS == 8, "pieces per wave per stage");
     static_assert(2 * PPS == G * 4, "one piece after every other k-step");
 
+    // the ring is filled first: its HBM latency runs under the loading of Q below
+    if (my_tiles > 0)
+        for (int st = 0; st < NST; ++st) {
+            next_fill(st);
+            issue_all();
+        }
+
     // ---- the stationary operand: this wave's 64 queries, all of K, as B fragments ----------------------
     FT qf[2][KST];
     float thr[2];
@@ -336,10 +343,6 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         t0r = __builtin_amdgcn_s_memrealtime();
     }
     if (my_tiles > 0) {
-        for (int st = 0; st < NST; ++st) {
-            next_fill(st);
-            issue_all();
-        }
         FT fa0, fa1, fb0, fb1;  // A fragments of the current / next k-step (two row blocks each)
         wait_vmcnt<(NST - 1) * PPS>();
         __builtin_amdgcn_s_barrier();

@@ -151,10 +151,9 @@ class EmbeddingManager:
         """embedder.py:736-742."""
         return hashlib.md5(text.encode("utf-8")).hexdigest()
 
-    async def _embed_matrix(self, texts: Sequence[str], rows_per_pass: int) -> np.ndarray:
-        """[len(texts), dim] float32: cached rows reused, the rest encoded `rows_per_pass` texts at a time, every
-        row at its text's position (embedder.py:301-332 partitions, encodes the misses, caches them, restores order).
-        A cached value of length 0 counts as a miss, as the reference's truthiness test does (:306)."""
+    def _lookup(self, texts: Sequence[str]):
+        """cache pass over `texts`: (rows with the hits filled in, positions still to encode, their cache keys).
+        A cached value of length 0 counts as a miss, as the reference's truthiness test does (embedder.py:306)."""
         rows: List[Optional[np.ndarray]] = [None] * len(texts)
         todo: List[int] = []
         keys: Dict[int, str] = {}
@@ -166,21 +165,34 @@ class EmbeddingManager:
                     rows[at] = np.asarray(seen, dtype=np.float32)
                     continue
             todo.append(at)
-        for lo in range(0, len(todo), max(1, rows_per_pass)):
-            part = todo[lo: lo + max(1, rows_per_pass)]
-            async with self._encode_lock:
-                fresh = await asyncio.to_thread(self.text_model.encode, [texts[at] for at in part])
-            fresh = np.asarray(fresh, dtype=np.float32)
-            for at, row in zip(part, fresh):
-                rows[at] = row
-                if self.cache:
-                    self.cache.put(keys[at], row)
-        self.stats["total_embeddings_created"] += len(todo)
+        return rows, todo, keys
+
+    def _encode_into(self, texts: Sequence[str], rows, part: List[int], keys: Dict[int, str]):
+        """one encoder pass (blocking): the texts at positions `part` -> their rows, and into the cache"""
+        fresh = np.asarray(self.text_model.encode([texts[at] for at in part]), dtype=np.float32)
+        for at, row in zip(part, fresh):
+            rows[at] = row
+            if self.cache:
+                self.cache.put(keys[at], row)
+
+    def _stack(self, rows, n_new: int) -> np.ndarray:
+        self.stats["total_embeddings_created"] += n_new
         if self.cache:
             self.stats["cache_hits"], self.stats["cache_misses"] = self.cache.hits, self.cache.misses
         if not rows:
             return np.zeros((0, self.get_embedding_dimension()), dtype=np.float32)
         return np.stack(rows)
+
+    async def _embed_matrix(self, texts: Sequence[str], rows_per_pass: int) -> np.ndarray:
+        """[len(texts), dim] float32: cached rows reused, the rest encoded `rows_per_pass` texts at a time (each pass
+        in a worker thread), every row at its text's position (embedder.py:301-332 partitions, encodes the misses,
+        caches them, restores the order)."""
+        rows, todo, keys = self._lookup(texts)
+        step = max(1, rows_per_pass)
+        for lo in range(0, len(todo), step):
+            async with self._encode_lock:
+                await asyncio.to_thread(self._encode_into, texts, rows, todo[lo: lo + step], keys)
+        return self._stack(rows, len(todo))
 
     async def embed_texts_batch(self, texts: List[str], show_progress: bool = None) -> List[List[float]]:
         """embedder.py:266-383: lists of Python floats, input order, misses encoded in slices of `batch_size`."""
@@ -247,19 +259,31 @@ class EmbeddingManager:
         self._dispatcher = QueryDispatcher(self.batch_query, max_batch=max_batch, max_wait_ms=max_wait_ms)
         return self._dispatcher
 
-    async def _search(self, matrix: np.ndarray, n_results: int, filter_dict: Optional[Dict]) -> List[Dict[str, Any]]:
-        """one collection.query for all rows of `matrix` (embedder.py:595-601), split into one dict per query (:604-609)"""
-        res = await self._engine_call("Query", self.collection.query, query_embeddings=matrix, n_results=n_results,
-                                      where=filter_dict, include=["metadatas", "documents", "distances"])
-        out = []
-        for b in range(len(matrix)):
-            out.append({key: (res[key][b] if res.get(key) else []) for key in RESULT_KEYS})
-        return out
+    _INCLUDE = ["metadatas", "documents", "distances"]
+
+    @staticmethod
+    def _split(res: Dict[str, Any], n: int) -> List[Dict[str, Any]]:
+        """collection.query's lists of lists -> one dict per query (embedder.py:604-609)"""
+        return [{key: (res[key][b] if res.get(key) else []) for key in RESULT_KEYS} for b in range(n)]
+
+    def _answer(self, texts: Sequence[str], n_results: int, filter_dict: Optional[Dict]) -> List[Dict[str, Any]]:
+        """Blocking, runs in ONE worker thread: cache lookups, ONE encoder pass for the misses, ONE collection.query
+        for all of them (embedder.py:566 + :595-601).  One thread hop per request instead of one per stage."""
+        rows, todo, keys = self._lookup(texts)
+        if todo:
+            self._encode_into(texts, rows, todo, keys)
+        matrix = self._stack(rows, len(todo))
+        res = self.collection.query(query_embeddings=matrix, n_results=n_results, where=filter_dict,
+                                    include=self._INCLUDE)
+        return self._split(res, len(texts))
 
     async def _query_with_retry(self, query_embedding: List[float], n_results: int,
                                 filter_dict: Optional[Dict]) -> Dict[str, Any]:
-        """embedder.py:585-617."""
-        return (await self._search(np.asarray([query_embedding], dtype=np.float32), n_results, filter_dict))[0]
+        """embedder.py:585-617: search for one ready-made vector."""
+        matrix = np.asarray([query_embedding], dtype=np.float32)
+        res = await self._engine_call("Query", self.collection.query, query_embeddings=matrix, n_results=n_results,
+                                      where=filter_dict, include=self._INCLUDE)
+        return self._split(res, 1)[0]
 
     async def query(self, query_text: str, n_results: int = 5, filter_dict: Optional[Dict] = None) -> Dict[str, Any]:
         """embedder.py:539-583."""
@@ -269,7 +293,7 @@ class EmbeddingManager:
         if self._dispatcher is not None:
             return await self._dispatcher.submit(query_text, n_results, filter_dict)
         try:
-            hit = (await self._search(await self._embed_matrix([query_text], 1), n_results, filter_dict))[0]
+            hit = (await self._engine_call("Query", self._answer, [query_text], n_results, filter_dict))[0]
         except Exception as e:
             logger.error("Query failed: %s", e, exc_info=True)
             raise
@@ -291,8 +315,9 @@ class EmbeddingManager:
             answers[at] = failed("Query text cannot be empty")
         if live:
             try:
-                matrix = await self._embed_matrix([queries[at] for at in live], len(live))
-                for at, hit in zip(live, await self._search(matrix, n_results, filter_dict)):
+                hits = await self._engine_call("Batch query", self._answer, [queries[at] for at in live], n_results,
+                                               filter_dict)
+                for at, hit in zip(live, hits):
                     answers[at] = hit
                 self.stats["total_queries"] += len(live)
             except Exception as e:

@@ -226,31 +226,44 @@ class VectorIndex:
         self._alive_dev[torch.from_numpy(touched).to(self.device)] = torch.from_numpy(
             self._alive_host[touched].view(np.int32)).to(self.device)
 
-    def _check_unit_norm(self, t: torch.Tensor, what: str):
-        if t.shape[0] == 0:
-            return
-        nrm = torch.linalg.vector_norm(t, dim=1)
-        bad = (nrm - 1.0).abs() > 1e-2
-        if bool(bad.any()):
-            i = int(torch.nonzero(bad)[0])
-            raise ValueError(f"{what}: row {i} has norm {float(nrm[i]):.4f}; this collection is cosine "
-                             f"(inner product of unit vectors) -- L2-normalise the vectors first")
+    @staticmethod
+    def _bad_norm(what: str, i: int, nrm: float):
+        return ValueError(f"{what}: row {i} has norm {nrm:.4f}; this collection is cosine (inner product of unit "
+                          f"vectors) -- L2-normalise the vectors first")
 
-    def _to_device_f32(self, x) -> torch.Tensor:
+    def _to_device_f32(self, x, what: str = "vectors") -> torch.Tensor:
+        """[m, dim] float32 on the device; unit norm is checked where the data already is (host arrays on the host:
+        a device-side check would put a synchronisation into every single-query call)"""
         if isinstance(x, torch.Tensor):
             t = x
-        else:
-            t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
-        if t.dim() == 1:
-            t = t.unsqueeze(0)
+            if t.dim() == 1:
+                t = t.unsqueeze(0)
+            if t.dim() == 2 and t.shape[0] and t.is_cuda:
+                nrm = torch.linalg.vector_norm(t.float(), dim=1)
+                bad = (nrm - 1.0).abs() > 1e-2
+                if bool(bad.any()):
+                    i = int(torch.nonzero(bad)[0])
+                    raise self._bad_norm(what, i, float(nrm[i]))
+            elif t.dim() == 2 and t.shape[0]:
+                x = t.numpy()
+        if not isinstance(x, torch.Tensor):
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+            if a.ndim == 1:
+                a = a[None, :]
+            if a.ndim == 2 and a.shape[0]:
+                nrm = np.sqrt(np.einsum("ij,ij->i", a, a))
+                bad = np.abs(nrm - 1.0) > 1e-2
+                if bad.any():
+                    i = int(np.argmax(bad))
+                    raise self._bad_norm(what, i, float(nrm[i]))
+            t = torch.from_numpy(a)
         if t.dim() != 2 or t.shape[1] != self.dim:
             raise ValueError(f"embedding dimension {tuple(t.shape)} does not match collection dimensionality {self.dim}")
         return t.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
 
     def _pack_queries(self, q) -> torch.Tensor:
         """float32 [B, d] -> storage dtype [B, ld] with zero pad columns (device-side cast kernel)."""
-        qf = self._to_device_f32(q)
-        self._check_unit_norm(qf, "query")
+        qf = self._to_device_f32(q, "query")
         packed = torch.empty((qf.shape[0], self.ld), dtype=self.dtype, device=self.device)
         _native.append_rows(packed, 0, qf, self.dim)
         return packed
@@ -260,8 +273,7 @@ class VectorIndex:
             metadatas: Optional[Sequence[Dict[str, Any]]] = None, ids: Optional[Sequence[str]] = None):
         if ids is None:
             raise ValueError("ids are required")
-        emb = self._to_device_f32(embeddings)
-        self._check_unit_norm(emb, "add")
+        emb = self._to_device_f32(embeddings, "add")
         m = emb.shape[0]
         if len(ids) != m:
             raise ValueError(f"{len(ids)} ids for {m} embeddings")

@@ -135,4 +135,4 @@ def test_manager_persists_across_restarts_when_asked(tmp_path, monkeypatch):
     n, r2 = asyncio.run(second())
     import numpy as np
 
-    assert n == 40 and r1["ids"] == r2["ids"] and np.allclose(r1["distances"], r2["distances"], atol=1e-5)
+    assert n == 40 and r1["ids"] == r2["ids"] and np.allclose(r1["distances"], r2["distances"], atol=1e-4)   # (a cached batch-of-40 embedding vs a fresh batch-of-1 one)
