@@ -444,6 +444,260 @@ __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// linear, persistent form for big problems (>= one 256x256 tile per CU): one workgroup per CU walks its tiles.
+//
+// Why: in linear_kernel a CU sits idle from the last MFMA of a tile until its 128 KB of output has been
+// accepted by the memory system AND the next workgroup has filled its ring (8.7 us of 29 us per tile at K = 768:
+// every CU stores at the same moment, 32 MB in a burst).  Here
+//   * the ring never stops: the first K-slabs of the NEXT tile are requested before the last MFMAs of this one,
+//   * MFMA orientation is D[token][feature] with the weight rows of a wave's 64-feature block interleaved at
+//     DMA time (LDS row j of the block = feature 2j, row 32+j = feature 2j+1), so a lane owns two ADJACENT
+//     features of a token: the tile goes from the accumulators to memory as 4-byte stores that cover whole
+//     128-byte lines per half-wave -- no LDS staging, no barrier, and the stores drain under the next main loop.
+// Same ring, swizzle and fragment reads as linear_kernel<256, 256, 4, 4, 2, true>.
+// ---------------------------------------------------------------------------------------------
+// pin the order inside one (fragment reads of the next k-step, MFMAs of this k-step) group: a read, its share of the MFMAs, ...
+template <int READS, int MFMAS, int I = 0>
+__device__ inline void interleave_reads_mfmas() {
+    if constexpr (I < READS) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (MFMAS * (I + 1)) / READS - (MFMAS * I) / READS, 0);
+        interleave_reads_mfmas<READS, MFMAS, I + 1>();
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NWF, int NWT>  // waves along the features x waves along the tokens of the 256x256 tile
+__global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(const LinearParams p, const int n_tiles,
+                                                                            const int tiles_f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BF = 256, BT = 256;
+    constexpr int NW = NWF * NWT;
+    constexpr int FT = BF / (32 * NWF);   // MFMA tiles along the features per wave (pairs of them interleave)
+    constexpr int TT = BT / (32 * NWT);   // MFMA tiles along the tokens per wave
+    constexpr int WAVE_F = BF / NWF, WAVE_T = BT / NWT;
+    constexpr int STAGE = (BF + BT) * SLAB;
+    constexpr int PW = 64 / NW;           // DMA pieces per wave per ring item: first half of the waves fetch W, second half x
+    constexpr int STORES = (FT / 2) * TT * 16;
+    static_assert(FT % 2 == 0 && PW >= 4, "layout");
+    constexpr int STORES_WAIT = STORES < 63 ? STORES : 63;  // vmcnt is a 6-bit counter
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wf = wave / NWT, wt_ = wave % NWT;
+    const int r32 = lane & 31, h = lane >> 5;
+    const unsigned RB = (unsigned)p.K * 2u;
+    const int nk = (int)(RB / SLAB);
+    const bool loads_w = wave < NW / 2;
+    const int lw = wave % (NW / 2);       // index among the waves that fetch the same operand
+
+    // LDS row prow of the W tile holds feature perm(prow): inside each block of 64 rows, row j <-> feature 2j,
+    // row 32+j <-> feature 2j+1.  Pieces of a wave: rows lw*PW*8 + i*8 + lane/8; the source offset of piece i
+    // differs from that of piece (i & 1) by a multiple of 16 rows (swizzle period) -> two VGPRs + scalar steps.
+    unsigned src_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int prow = (lw * PW + i) * 8 + (lane >> 3);
+        const int srow = loads_w ? ((prow & ~63) | ((prow & 31) << 1) | ((prow >> 5) & 1)) : prow;
+        src_off[i] = __umul24((unsigned)srow, RB) + (unsigned)(((lane & 7) ^ ((prow >> 1) & 7)) * 16);   // (K < 2^23)
+    }
+    // piece i = 2q + (i&1): LDS rows advance by 16q
+    auto piece_src_rows = [&](int i) -> int {
+        const int q = i >> 1;
+        if (!loads_w) return 16 * q;
+        return (q >> 2) * 64 + ((q >> 1) & 1) + (q & 1) * 32;   // 16 LDS rows on = 32 features on; 32 rows on = the odd features; 64 = next block
+    };
+    char *const my_dst = smem + (loads_w ? 0 : BF * SLAB) + lw * PW * 1024;
+
+    auto tile_origin = [&](int v, int &f0, int &t0) {   // virtual block id -> tile, XCD-banded like linear_kernel
+        int lid = v;
+        if (p.xcd_order) {
+            const int per = n_tiles / 8, rem = n_tiles % 8;
+            const int xcd = v % 8, idx = v / 8;
+            lid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+        }
+        f0 = (lid % tiles_f) * BF;
+        t0 = (lid / tiles_f) * BT;
+    };
+    auto my_source = [&](int v, const char *&base, unsigned &bytes) {   // what this wave fetches of tile v
+        if (v >= n_tiles) {
+            base = p.x;
+            bytes = 0;
+            return;
+        }
+        int f0, t0;
+        tile_origin(v, f0, t0);
+        if (loads_w) {
+            const int left = p.N - f0;
+            base = p.wt + (size_t)f0 * RB;
+            bytes = (unsigned)((left < BF ? left : BF) * (long long)RB);
+        } else {
+            const int left = p.M - t0;
+            base = p.x + ((p.dbg & DBG_LINEAR_X_SAME) ? (size_t)0 : (size_t)t0 * RB);
+            bytes = (unsigned)((left < BT ? left : BT) * (long long)RB);
+        }
+    };
+    auto issue = [&](const char *base, unsigned bytes, int stage, int kslab) {
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
+        char *dst = my_dst + stage * STAGE;
+        const unsigned koff = (unsigned)kslab * SLAB;
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + i * 1024), 16, src_off[i & 1],
+                                                     koff + (unsigned)piece_src_rows(i) * RB, 0, 0);
+    };
+
+    const int sw = (r32 >> 1) & 7;
+    const int w_base = (wf * WAVE_F + r32) * SLAB;               // + 32 rows per MFMA tile
+    const int x_base = BF * SLAB + (wt_ * WAVE_T + r32) * SLAB;
+
+    half8_t fw[2][FT], fx[2][TT];
+    auto load = [&](half8_t(&w_)[FT], half8_t(&x_)[TT], const char *st, int m) {
+        const int off = ((2 * m + h) ^ sw) * 16;
+#pragma unroll
+        for (int b = 0; b < TT; ++b) x_[b] = *(const half8_t *)(st + x_base + b * (32 * SLAB) + off);
+#pragma unroll
+        for (int a = 0; a < FT; ++a) w_[a] = *(const half8_t *)(st + w_base + a * (32 * SLAB) + off);
+    };
+    // acc[a][b]: a = 2*block + parity; register r <-> token 8*(r/4) + 4*h + r%4 of token tile b; lane j <-> features
+    // 64*block + 2j + parity
+    f32x16_t acc[FT][TT];
+    auto mma = [&](const half8_t(&w_)[FT], const half8_t(&x_)[TT]) {
+#pragma unroll
+        for (int a = 0; a < FT; ++a)
+#pragma unroll
+            for (int b = 0; b < TT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x_[b], w_[a], acc[a][b], 0, 0, 0);
+    };
+    auto interleave = [&]() { interleave_reads_mfmas<FT + TT, FT * TT>(); };
+
+    int v = blockIdx.x;
+    const char *cur_base, *nxt_base;
+    unsigned cur_bytes, nxt_bytes;
+    my_source(v, cur_base, cur_bytes);
+    my_source(v + (int)gridDim.x, nxt_base, nxt_bytes);
+    // ring prologue: items 0 and 1 of the first tile (nk >= 2 is the launcher's condition)
+    issue(cur_base, cur_bytes, 0, 0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    issue(cur_base, cur_bytes, 1, 1);
+    int g = 0;  // ring items consumed so far (stage = g & 1)
+
+    for (; v < n_tiles; v += (int)gridDim.x) {
+        int f0, t0;
+        tile_origin(v, f0, t0);
+#pragma unroll
+        for (int a = 0; a < FT; ++a)
+#pragma unroll
+            for (int b = 0; b < TT; ++b)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.0f;
+
+        load(fw[0], fx[0], smem + (g & 1) * STAGE, 0);
+        for (int it = 0; it < nk; ++it, ++g) {
+            const char *st = smem + (g & 1) * STAGE;
+            load(fw[1], fx[1], st, 1);
+            mma(fw[0], fx[0]);
+            interleave();
+            load(fw[0], fx[0], st, 2);
+            mma(fw[1], fx[1]);
+            interleave();
+            load(fw[1], fx[1], st, 3);
+            mma(fw[0], fx[0]);
+            interleave();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of this stage are complete
+            // item g+1 has landed.  vmcnt retires in issue order: in the first iteration after an epilogue the
+            // stores of the previous tile are YOUNGER than item g+1 and may stay in flight
+            if (it == 0 && g != 0) wait_vmcnt<STORES_WAIT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            {   // item g+2 goes into the stage every wave has just finished reading
+                const int k2 = it + 2;
+                if (k2 < nk) issue(cur_base, cur_bytes, g & 1, k2);
+                else if (nxt_bytes != 0) issue(nxt_base, nxt_bytes, g & 1, k2 - nk);
+            }
+            if (it + 1 < nk) load(fw[0], fx[0], smem + ((g + 1) & 1) * STAGE, 0);
+            mma(fw[1], fx[1]);
+            interleave();
+        }
+        cur_base = nxt_base;
+        cur_bytes = nxt_bytes;
+        my_source(v + 2 * (int)gridDim.x, nxt_base, nxt_bytes);
+
+        // ---- epilogue: accumulators -> memory, no LDS ------------------------------------------
+        // address = per-lane part (feature pair, +4 rows for the upper half-wave) in the VGPR offset, the
+        // register's row in the scalar offset.  Only the VGPR offset is range-checked by the buffer unit, so a
+        // ragged last token tile takes the form that adds the row into the VGPR offset.  Stores are non-temporal:
+        // default-policy stores of 32 MB per round push the W and x tiles out of the L2s (-6 % on the K = 768 shapes).
+        if (p.dbg & DBG_LINEAR_SKIP_EPILOGUE) continue;   // timing only
+        // (lane-derived values are recomputed here behind an opaque copy: hoisted out of the tile loop they would
+        // sit in VGPRs through the main loop, which has none to spare at 16 waves)
+        unsigned lane_e = (unsigned)lane;
+        asm volatile("" : "+v"(lane_e));
+        const int r32e = (int)(lane_e & 31u), he = (int)(lane_e >> 5);
+        const int rows = p.M - t0 < BT ? p.M - t0 : BT;
+        const unsigned row_b = (unsigned)p.N * 2u;
+        const unsigned valid = (unsigned)rows * row_b;
+        const unsigned wrow_b = (unsigned)(wt_ * WAVE_T) * row_b;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)t0 * p.N, (p.dbg & DBG_LINEAR_DROP_STORES) ? 0u : valid);
+        const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.resid != nullptr ? p.resid + (size_t)t0 * p.N : p.out, p.resid != nullptr ? valid : 0u);
+        auto finish = [&](auto act_tag, auto res_tag, auto ragged_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool RES = decltype(res_tag)::value;
+            constexpr bool RAGGED = decltype(ragged_tag)::value;
+#pragma unroll
+            for (int blk = 0; blk < FT / 2; ++blk) {
+                const int fcol = f0 + wf * WAVE_F + blk * 64 + 2 * r32e;   // this lane's feature pair
+                const bool f_ok = fcol < p.N;                               // N is even
+                // (an out-of-range pair gets an offset that stays out of range with any row added)
+                const unsigned voff = f_ok ? (unsigned)(4 * he) * row_b + (unsigned)fcol * 2u : 0x80000000u;
+                float2 bias2 = make_float2(0.f, 0.f);
+                if (p.bias != nullptr && f_ok) bias2 = *(const float2 *)(p.bias + fcol);
+                unsigned rv[TT][16];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int b = 0; b < TT; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned ro = wrow_b + (unsigned)(b * 32 + 8 * (r >> 2) + (r & 3)) * row_b;
+                            rv[b][r] = RAGGED ? __builtin_amdgcn_raw_buffer_load_b32(rs_res, voff + ro, 0, 0)
+                                              : __builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, ro, 0);
+                        }
+                }
+#pragma unroll
+                for (int b = 0; b < TT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned ro = wrow_b + (unsigned)(b * 32 + 8 * (r >> 2) + (r & 3)) * row_b;
+                        // (the activated value is rounded to fp16 before the residual add, as in linear_kernel)
+                        half2_t o = f2h(act_apply<ACT>(acc[2 * blk][b][r] + bias2.x), act_apply<ACT>(acc[2 * blk + 1][b][r] + bias2.y));
+                        if constexpr (RES) o = o + __builtin_bit_cast(half2_t, rv[b][r]);
+                        if constexpr (RAGGED)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff + ro, 0, 2);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff, ro, 2);
+                    }
+            }
+        };
+        auto with_res = [&](auto act_tag) {
+            if (rows < BT) {
+                if (p.resid != nullptr) finish(act_tag, std::true_type{}, std::true_type{});
+                else finish(act_tag, std::false_type{}, std::true_type{});
+            } else {
+                if (p.resid != nullptr) finish(act_tag, std::true_type{}, std::false_type{});
+                else finish(act_tag, std::false_type{}, std::false_type{});
+            }
+        };
+        if (p.act == MMRAG_ACT_GELU) with_res(std::integral_constant<int, MMRAG_ACT_GELU>{});
+        else if (p.act == MMRAG_ACT_QUICK_GELU) with_res(std::integral_constant<int, MMRAG_ACT_QUICK_GELU>{});
+        else with_res(std::integral_constant<int, MMRAG_ACT_NONE>{});
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention (packed sequences): ctx[t, head*DH + d] = softmax(Q K^T * scale + mask) V
 // qkv is [T, 3H] fp16 (Q | K | V column blocks).  One workgroup = (128-query tile, head, seq),
 // 4 waves x 32 queries; keys are consumed in tiles of 64.
@@ -876,7 +1130,10 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
         // reads + XCD-aware tile order: another +4-15 % (A/B in one process, tools/linear_vs_rocblas.py)
         if (dbg & DBG_LINEAR_PLAIN)
             linear_kernel<256, 256, 4, 4, 2><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
-        else
+        else if (K >= 128 && N % 2 == 0 && !(dbg & DBG_LINEAR_NO_PERSIST)) {
+            const unsigned grid = (unsigned)(big_tiles < cus ? big_tiles : cus);
+            linear_persistent_kernel<2, 4><<<grid, 512, 0, s>>>(p, (int)big_tiles, (int)tiles_f);
+        } else
             linear_kernel<256, 256, 4, 4, 2, true><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
     } else {
         const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);

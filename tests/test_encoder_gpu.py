@@ -81,6 +81,27 @@ def test_linear_few_tokens_exact_integers(N):
         assert np.array_equal(out.float().cpu().numpy(), x @ w.T), (M, K, Nf)
 
 
+@pytest.mark.parametrize("M,K,Nf", [(22000, 768, 768), (8300, 128, 2304), (17000, 192, 1000), (65536, 64, 256)])
+@pytest.mark.parametrize("act,with_resid", [(0, False), (1, False), (0, True), (2, True)])
+def test_linear_one_tile_per_cu_and_more(N, M, K, Nf, act, with_resid):
+    """>= 256 tiles of 256x256: the persistent kernel (ragged last token tile, ragged last feature tile, the two-slab
+    minimum of its ring; K = 64 stays on the one-tile-per-workgroup kernel)"""
+    test_linear(N, M, K, Nf, act, with_resid)
+
+
+def test_linear_persistent_exact_integers(N):
+    """every (tile, wave, lane, register) of the persistent kernel's direct store lands on its own element"""
+    g = np.random.default_rng(5)
+    M, K, Nf = 66000, 192, 768
+    x = g.integers(-4, 5, (M, K)).astype(np.float32)
+    w = g.integers(-2, 3, (Nf, K)).astype(np.float32)
+    w[:, 0] += np.arange(Nf) % 7
+    x[:, 1] += np.arange(M) % 3
+    res = g.integers(-8, 9, (M, Nf)).astype(np.float32)
+    out = N.linear_f16(dev16(x), dev16(w), dev32(np.arange(Nf) % 4), 0, dev16(res))
+    assert np.array_equal(out.float().cpu().numpy(), x @ w.T + (np.arange(Nf) % 4) + res)
+
+
 def test_linear_exact_integers(N):
     """integer data is exact in fp16 x fp16 -> fp32: catches any fragment / epilogue index swap"""
     g = np.random.default_rng(0)

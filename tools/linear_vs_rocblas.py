@@ -6,8 +6,9 @@ import torch
 from multimodal_rag_amd import _native as N
 L = N.lib()
 L.mmrag_internal_set_debug.argtypes = [ctypes.c_uint]
-VARIANTS = {"default": 0, "plain": 1}
-def t(fn, iters=10):
+VARIANTS = {"default": 0, "one-tile-per-wg": 4, "drop-stores": 8, "no-epilogue": 16, "x-same": 128}
+CHECKED = ("default", "one-tile-per-wg")
+def t(fn, iters=800):   # ~0.2 s per measurement: the board throttles after a few ms of this load
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -15,7 +16,7 @@ def t(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 M = 65536
-for K, Nf in [(768, 2304), (768, 768), (768, 3072), (3072, 768)]:
+for K, Nf in [(768, 2304), (768, 768), (768, 3072), (3072, 768), (1536, 768)]:
     x = (torch.randn((M, K), device="cuda") * 0.5).half(); w = (torch.randn((Nf, K), device="cuda") * 0.05).half()
     b = torch.randn(Nf, device="cuda"); out = torch.empty((M, Nf), dtype=torch.float16, device="cuda")
     fl = 2.0 * M * K * Nf
@@ -24,8 +25,9 @@ for K, Nf in [(768, 2304), (768, 768), (768, 3072), (3072, 768)]:
         for name, flag in VARIANTS.items():
             L.mmrag_internal_set_debug(flag)
             res.setdefault(name, []).append(t(lambda: N.linear_f16(x, w, b, 0, None, out)))
-            if ref_out is None: ref_out = out.clone()
-            else: assert torch.equal(ref_out, out), name
+            if name in CHECKED:
+                if ref_out is None: ref_out = out.clone()
+                else: assert (ref_out.float() - out.float()).abs().max().item() < 0.02, name   # (K is walked from different slabs)
         L.mmrag_internal_set_debug(0)
         res.setdefault("hipBLASLt", []).append(t(lambda: torch.matmul(x, w.t())))
     line = " | ".join(f"{k} {sorted(v)[len(v)//2]:.1f} us {fl/sorted(v)[len(v)//2]/1e6:.0f} TF" for k, v in res.items())
