@@ -83,7 +83,7 @@ def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_b
         "config": {"workload": f"embed: bge-base-en-v1.5 shape (L12 H768 I3072, CLS pool), random-init fp16, "
                                f"{CHUNKS_PER_STEP} chunks x {SEQ} tokens per step per GPU, forward + append to shard",
                    "chunks_per_step_per_gpu": CHUNKS_PER_STEP, "seq_len": SEQ, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "linear_kernel (+ attention_kernel)",
+        "roofline": {"bound": "mfma", "kernel": "linear_persistent_kernel (+ attention_kernel)",
                      "achieved": round(tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
                      "flops_per_chunk": enc.flops_per_sequence(SEQ), "device_ms_per_step": round(dev_ms, 3)},

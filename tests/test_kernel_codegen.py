@@ -60,3 +60,23 @@ def test_tile_loop_has_no_spills_and_no_accvgpr_traffic(tmp_path):
             assert "v_accvgpr" not in l, f"{name}: Q fragments move between register files in the k-steps: {l.strip()}"
             assert not re.search(r"s_waitcnt.*vmcnt\(0\)", l) or "ASM" in l, f"{name}: vmcnt(0) among the k-steps"
     assert seen >= 6   # 2 dtypes x 3 row lengths (x 2 cache policies)
+
+
+def test_persistent_linear_kernel_has_no_scratch(tmp_path):
+    """csrc/encoder.hip, linear_persistent_kernel: its K loop carries 128 accumulator registers and two fragment sets
+    with an LDS-DMA ring in flight; a spill reload inside it waits vmcnt(0) and stalls the ring (seen with 16 waves of
+    128 registers: +15 %).  The 8-wave form must compile without any scratch."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "encoder.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-I",
+                        os.path.join(ROOT, "include"), os.path.join(ROOT, "multimodal_rag_amd", "csrc", "encoder.hip"),
+                        "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = open(out).read()
+    body = re.search(r"^(_ZN10mmrag_impl24linear_persistent_kernel\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
+    assert body, "linear_persistent_kernel not found"
+    assert "scratch_" not in body.group(2)
+    meta = re.search(r"\.name:\s+_ZN10mmrag_impl24linear_persistent_kernel.*?\.vgpr_spill_count:\s+(\d+)", asm, re.S)
+    assert meta and int(meta.group(1)) == 0
