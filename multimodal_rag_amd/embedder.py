@@ -27,6 +27,7 @@ from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
+from . import tracing
 from .config import settings
 from .engines import CLIP_MODEL_NAMES, ClipEngine, HipEngine, _is_clip_dir, load_item_image  # noqa: F401 (re-exported)
 from .hostutil import CountingLRU, call_with_retry
@@ -392,6 +393,11 @@ class EmbeddingManager:
         if self.cache:
             report["cache"] = self.cache.get_stats()
         return report
+
+    def get_stage_timers(self) -> Dict[str, Dict[str, float]]:
+        """Not in the reference (it only logs time.time() deltas): wall clock per stage of this process' requests --
+        tokenize / encode / search / collect, shard.* in the sharded service -- see tracing.py."""
+        return tracing.snapshot()
 
     async def get_stats(self) -> Dict[str, Any]:
         """api.py:472 calls this name; the reference class only defines get_collection_stats."""

@@ -14,6 +14,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from .config import settings
+from .tracing import stage
 
 logger = logging.getLogger(__name__)
 
@@ -55,10 +56,14 @@ class HipEngine:
 
     def encode(self, texts: List[str]) -> np.ndarray:
         if hasattr(self.tokenizer, "encode_batch_arrays"):   # native, multi-threaded tokenizer
-            out = self.encoder.encode_id_rows(*self.tokenizer.encode_batch_arrays(texts, self.max_seq_length))
-        else:
-            out = self.encoder.encode_ids([self.tokenizer.encode(t, self.max_seq_length) for t in texts])
-        return out.cpu().numpy()
+            with stage("tokenize"):
+                rows = self.tokenizer.encode_batch_arrays(texts, self.max_seq_length)
+            with stage("encode"):
+                return self.encoder.encode_id_rows(*rows).cpu().numpy()
+        with stage("tokenize"):
+            seqs = [self.tokenizer.encode(t, self.max_seq_length) for t in texts]
+        with stage("encode"):
+            return self.encoder.encode_ids(seqs).cpu().numpy()
 
     def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):
         from .index import VectorIndex

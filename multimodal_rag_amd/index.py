@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _native
+from .tracing import stage
 
 logger = logging.getLogger(__name__)
 
@@ -388,10 +389,14 @@ class VectorIndex:
         The lock is held only while the kernels are enqueued: concurrent callers (asyncio.to_thread workers,
         embedder.py:595) overlap their host waits and result building.  Row tables are append-only between
         compactions and a compaction swaps in NEW lists, so the snapshot taken under the lock stays valid."""
-        with self._lock:
+        with self._lock, stage("search"):
             scores, rows = self._launch_search(query_embeddings, n_results, where)
             ids_t, docs_t, metas_t = self._ids, self._documents, self._metadatas
             emb_src = self._matrix if "embeddings" in include else None
+        with stage("collect"):
+            return self._collect(scores, rows, include, ids_t, docs_t, metas_t, emb_src)
+
+    def _collect(self, scores, rows, include, ids_t, docs_t, metas_t, emb_src) -> Dict[str, Any]:
         scores = scores.cpu().numpy()
         rows = rows.cpu().numpy()
         out: Dict[str, Any] = {"ids": []}

@@ -33,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native
+from .tracing import stage
 
 logger = logging.getLogger(__name__)
 
@@ -257,15 +258,17 @@ class ShardedCollection:
         # the query matrix: a tensor broadcast on the control group's device (no pickling)
         qt = (q.to(self._ctl_device) if self.rank == 0 else torch.empty((B, d), dtype=torch.float32,
                                                                        device=self._ctl_device))
-        dist.broadcast(qt, src=0, group=self.control)
-        if has_where:
-            where = self._object(where)
+        with stage("shard.broadcast"):
+            dist.broadcast(qt, src=0, group=self.control)
+            if has_where:
+                where = self._object(where)
         nb = B * k
         nbytes = _native.packed_block_bytes(B, k)
         loc = torch.zeros(nbytes, dtype=torch.uint8)
         failure = None
         try:
-            scores, rows = self.shard.search(qt.cpu().numpy() if self._ctl_device.type == "cpu" else qt, k, where)
+            with stage("shard.search"):
+                scores, rows = self.shard.search(qt.cpu().numpy() if self._ctl_device.type == "cpu" else qt, k, where)
             scores = torch.as_tensor(scores).to(torch.float32)
             rows = torch.as_tensor(rows).to(torch.int64)
             kk = scores.shape[1]
@@ -290,19 +293,21 @@ class ShardedCollection:
             loc[:8].view(torch.int64)[0] = _FAILED_ROW
         loc = loc.to(self.device)
         all_ = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
-        dist.all_gather_into_tensor(all_, loc, group=self.group)
-        host = all_.cpu()
+        with stage("shard.exchange"):
+            dist.all_gather_into_tensor(all_, loc, group=self.group)
+            host = all_.cpu()
         heads = host.view(self.world, nbytes)[:, :8].contiguous().view(torch.int64).reshape(-1)
         if bool((heads == _FAILED_ROW).any()):
             msgs = self._gather(failure)        # every rank saw the marker: they all come here
             if self.rank != 0:
                 return None
             raise ShardError("query failed on " + "; ".join(f"rank {g}: {m}" for g, m in enumerate(msgs) if m))
-        if k <= _native.MAX_K:
-            top_s, top_r = _native.merge_topk_host_packed(host, self.world, B, k, k)
-            top_s, top_r = top_s.numpy(), top_r.numpy()
-        else:
-            top_s, top_r = _merge_deep(host, self.world, B, k)
+        with stage("shard.merge"):
+            if k <= _native.MAX_K:
+                top_s, top_r = _native.merge_topk_host_packed(host, self.world, B, k, k)
+                top_s, top_r = top_s.numpy(), top_r.numpy()
+            else:
+                top_s, top_r = _merge_deep(host, self.world, B, k)
         # describe the winning rows this rank owns (the only pickled part of a query: k rows' payload per query)
         mine: Dict[int, Dict[str, Any]] = {}
         owned = sorted({int(sq) for sq in top_r.reshape(-1) if sq >= 0 and int(sq) in self._id_of})
@@ -316,7 +321,8 @@ class ShardedCollection:
                             "metadata": got["metadatas"][j] if got.get("metadatas") is not None else None,
                             "document": got["documents"][j] if got.get("documents") is not None else None,
                             "embedding": got["embeddings"][j] if got.get("embeddings") is not None else None}
-        payloads = self._gather(mine)
+        with stage("shard.payload"):
+            payloads = self._gather(mine)
         if self.rank != 0:
             return None
         out: Dict[str, Any] = {"ids": []}

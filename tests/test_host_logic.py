@@ -316,3 +316,34 @@ def test_meta_index_equals_full_scan():
     for w in [{"page": {"$gt": 2}}, {"page": {"$ne": 1}}, {"tags": ["a", "b"]}, {"page": None}, {"type": {"$nin": ["text"]}}]:
         got = idx.rows(w)
         assert got is None or got.tolist() == [i for i, m in enumerate(metas) if match_where(m, w)], w
+
+
+def test_stage_timers_and_stats_key(monkeypatch):
+    """tracing.stage: per-stage wall clock (always on), read through EmbeddingManager.get_stage_timers(); roctx stays off unless
+    MMRAG_ROCTX=1, and a missing library only turns the ranges off"""
+    import asyncio
+    import time as _time
+
+    from multimodal_rag_amd import tracing
+
+    tracing.reset()
+    with tracing.stage("unit.a"):
+        _time.sleep(0.01)
+    with tracing.stage("unit.a"):
+        pass
+    try:
+        with tracing.stage("unit.b"):
+            raise RuntimeError("stage bodies may raise")
+    except RuntimeError:
+        pass
+    snap = tracing.snapshot()
+    assert snap["unit.a"]["calls"] == 2 and snap["unit.a"]["total_s"] >= 0.009 and snap["unit.a"]["max_ms"] >= 9.0
+    assert snap["unit.b"]["calls"] == 1
+    assert not tracing.roctx_enabled()
+
+    m = EmbeddingManager(engine=FakeEngine(), enable_cache=False)
+    asyncio.run(m.embed_and_store([{"id": "text_0", "summary": "alpha beta", "raw": "", "type": "text"}], "doc_aaaaaaaaaaaa"))
+    asyncio.run(m.query("alpha"))
+    assert "unit.a" in m.get_stage_timers()
+    tracing.reset()
+    assert tracing.snapshot() == {}

@@ -407,3 +407,29 @@ def test_dispatcher_batches_concurrent_queries_on_the_hip_engine(gpu):
                                 er, es)
         if i >= 88:
             assert all(mm["type"] == "table" for mm in res["metadatas"])
+
+
+@pytest.mark.gpu
+def test_stage_timers_and_roctx_ranges_on_the_hip_path(gpu):
+    """MMRAG_ROCTX=1: every stage of a query pushes a roctx range (libroctx64 from the ROCm image) and the timers name
+    the stages of the served path"""
+    import subprocess
+    import sys
+
+    code = (
+        "import asyncio\n"
+        "from multimodal_rag_amd import tracing\n"
+        "from multimodal_rag_amd.embedder import EmbeddingManager, HipEngine\n"
+        "m = EmbeddingManager(engine=HipEngine('sentence-transformers/all-MiniLM-L6-v2'), enable_cache=False)\n"
+        "items = [{'id': f'text_{i}', 'summary': f'passage {i}', 'raw': '', 'type': 'text'} for i in range(8)]\n"
+        "asyncio.run(m.embed_and_store(items, 'doc_aaaaaaaaaaaa'))\n"
+        "r = asyncio.run(m.query('passage 3', n_results=2))\n"
+        "assert tracing.roctx_enabled(), 'libroctx64 not loaded'\n"
+        "s = m.get_stage_timers()\n"
+        "assert {'tokenize', 'encode', 'search', 'collect'} <= set(s), s\n"
+        "assert all(v['calls'] >= 1 and v['total_s'] > 0 for v in s.values()), s\n"
+        "print('ok', len(r['ids']))\n")
+    env = dict(os.environ, MMRAG_ROCTX="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok 2" in out.stdout, out.stderr[-1500:]
