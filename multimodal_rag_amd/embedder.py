@@ -271,6 +271,18 @@ class EmbeddingManager:
         """Blocking, runs in ONE worker thread: cache lookups, ONE encoder pass for the misses, ONE collection.query
         for all of them (embedder.py:566 + :595-601).  One thread hop per request instead of one per stage."""
         rows, todo, keys = self._lookup(texts)
+        if (len(todo) == len(texts) and texts and hasattr(self.text_model, "encode_device")
+                and getattr(self.collection, "accepts_device_queries", False)):
+            # nothing cached: the embeddings go from the encoder to the search kernel on the device; the host does not
+            # wait in between and reads them back (for the cache) only after the answer is there
+            dev = self.text_model.encode_device(list(texts))
+            res = self.collection.query(query_embeddings=dev, n_results=n_results, where=filter_dict,
+                                        include=self._INCLUDE, check_norm=False)
+            if self.cache:
+                for at, row in zip(todo, dev.cpu().numpy()):
+                    self.cache.put(keys[at], row)
+            self._stack([], len(todo))
+            return self._split(res, len(texts))
         if todo:
             self._encode_into(texts, rows, todo, keys)
         matrix = self._stack(rows, len(todo))

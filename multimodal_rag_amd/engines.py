@@ -65,6 +65,19 @@ class HipEngine:
         with stage("encode"):
             return self.encoder.encode_ids(seqs).cpu().numpy()
 
+    def encode_device(self, texts: List[str]):
+        """the same embeddings as encode(), left on the device ([n, dim] float32): the query path hands them straight
+        to the search kernel, with no device -> host -> device round trip and no host wait in between"""
+        if hasattr(self.tokenizer, "encode_batch_arrays"):
+            with stage("tokenize"):
+                rows = self.tokenizer.encode_batch_arrays(texts, self.max_seq_length)
+            with stage("encode"):
+                return self.encoder.encode_id_rows(*rows)
+        with stage("tokenize"):
+            seqs = [self.tokenizer.encode(t, self.max_seq_length) for t in texts]
+        with stage("encode"):
+            return self.encoder.encode_ids(seqs)
+
     def new_collection(self, name: str, metadata: Optional[Dict[str, Any]] = None):
         from .index import VectorIndex
 

@@ -232,20 +232,20 @@ class VectorIndex:
         return ValueError(f"{what}: row {i} has norm {nrm:.4f}; this collection is cosine (inner product of unit "
                           f"vectors) -- L2-normalise the vectors first")
 
-    def _to_device_f32(self, x, what: str = "vectors") -> torch.Tensor:
+    def _to_device_f32(self, x, what: str = "vectors", check_norm: bool = True) -> torch.Tensor:
         """[m, dim] float32 on the device; unit norm is checked where the data already is (host arrays on the host:
         a device-side check would put a synchronisation into every single-query call)"""
         if isinstance(x, torch.Tensor):
             t = x
             if t.dim() == 1:
                 t = t.unsqueeze(0)
-            if t.dim() == 2 and t.shape[0] and t.is_cuda:
+            if t.dim() == 2 and t.shape[0] and t.is_cuda and check_norm:
                 nrm = torch.linalg.vector_norm(t.float(), dim=1)
                 bad = (nrm - 1.0).abs() > 1e-2
                 if bool(bad.any()):
                     i = int(torch.nonzero(bad)[0])
                     raise self._bad_norm(what, i, float(nrm[i]))
-            elif t.dim() == 2 and t.shape[0]:
+            elif t.dim() == 2 and t.shape[0] and not t.is_cuda:
                 x = t.numpy()
         if not isinstance(x, torch.Tensor):
             a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
@@ -262,9 +262,9 @@ class VectorIndex:
             raise ValueError(f"embedding dimension {tuple(t.shape)} does not match collection dimensionality {self.dim}")
         return t.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
 
-    def _pack_queries(self, q) -> torch.Tensor:
+    def _pack_queries(self, q, check_norm: bool = True) -> torch.Tensor:
         """float32 [B, d] -> storage dtype [B, ld] with zero pad columns (device-side cast kernel)."""
-        qf = self._to_device_f32(q, "query")
+        qf = self._to_device_f32(q, "query", check_norm)
         packed = torch.empty((qf.shape[0], self.ld), dtype=self.dtype, device=self.device)
         _native.append_rows(packed, 0, qf, self.dim)
         return packed
@@ -343,11 +343,11 @@ class VectorIndex:
         words = torch.from_numpy(np.packbits(flags, bitorder="little").view(np.int32)).to(self.device)
         return torch.bitwise_and(words, self._alive_dev) if self._n_dead else words
 
-    def _launch_search(self, query_embeddings, n_results: int, where):
+    def _launch_search(self, query_embeddings, n_results: int, where, check_norm: bool = True):
         """enqueue the search (caller holds the lock); returns device tensors, no host sync"""
         if n_results < 1:
             raise ValueError("n_results must be >= 1")
-        q = self._pack_queries(query_embeddings)
+        q = self._pack_queries(query_embeddings, check_norm)
         bits = self._where_bits(where)
         if n_results <= _native.MAX_K:
             return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
@@ -382,36 +382,42 @@ class VectorIndex:
         with self._lock:
             return self._launch_search(query_embeddings, n_results, where)
 
+    accepts_device_queries = True   # query() takes a device tensor as it is (EmbeddingManager's no-round-trip path)
+
     def query(self, query_embeddings, n_results: int = 10, where: Optional[Dict[str, Any]] = None,
-              include: Sequence[str] = ("metadatas", "documents", "distances")) -> Dict[str, Any]:
+              include: Sequence[str] = ("metadatas", "documents", "distances"), check_norm: bool = True) -> Dict[str, Any]:
         """Chroma-shaped result: lists of lists, ascending distance = 1 - cos, at most count() hits.
+        `check_norm=False` (not in Chroma): the caller vouches for unit-norm rows -- the engine's own embeddings on the
+        device, where the check would cost a host synchronisation per call.
 
         The lock is held only while the kernels are enqueued: concurrent callers (asyncio.to_thread workers,
         embedder.py:595) overlap their host waits and result building.  Row tables are append-only between
         compactions and a compaction swaps in NEW lists, so the snapshot taken under the lock stays valid."""
         with self._lock, stage("search"):
-            scores, rows = self._launch_search(query_embeddings, n_results, where)
+            scores, rows = self._launch_search(query_embeddings, n_results, where, check_norm)
             ids_t, docs_t, metas_t = self._ids, self._documents, self._metadatas
             emb_src = self._matrix if "embeddings" in include else None
         with stage("collect"):
             return self._collect(scores, rows, include, ids_t, docs_t, metas_t, emb_src)
 
     def _collect(self, scores, rows, include, ids_t, docs_t, metas_t, emb_src) -> Dict[str, Any]:
-        scores = scores.cpu().numpy()
-        rows = rows.cpu().numpy()
-        out: Dict[str, Any] = {"ids": []}
-        for key in ("distances", "metadatas", "documents", "embeddings"):
-            out[key] = [] if key in include else None
-        for b in range(rows.shape[0]):
-            hit = [int(r) for r in rows[b] if r >= 0]
+        # one device -> host copy each, then plain Python lists: per-element numpy scalars cost 10x a list item
+        rows_l = rows.cpu().tolist()
+        dist_l = (1.0 - scores).cpu().tolist() if "distances" in include else None   # float32 arithmetic, as before
+        want_m, want_d, want_e = "metadatas" in include, "documents" in include, "embeddings" in include
+        out: Dict[str, Any] = {"ids": [], "distances": [] if dist_l is not None else None,
+                               "metadatas": [] if want_m else None, "documents": [] if want_d else None,
+                               "embeddings": [] if want_e else None}
+        for b, row in enumerate(rows_l):
+            hit = [r for r in row if r >= 0]            # misses (-1) only trail
             out["ids"].append([ids_t[r] for r in hit])
-            if "distances" in include:
-                out["distances"].append([float(np.float32(1.0) - scores[b, j]) for j in range(len(hit))])
-            if "metadatas" in include:
+            if dist_l is not None:
+                out["distances"].append(dist_l[b][:len(hit)])
+            if want_m:
                 out["metadatas"].append([dict(metas_t[r]) for r in hit])
-            if "documents" in include:
+            if want_d:
                 out["documents"].append([docs_t[r] for r in hit])
-            if "embeddings" in include:
+            if want_e:
                 out["embeddings"].append(self._fetch(hit, emb_src))
         return out
 
