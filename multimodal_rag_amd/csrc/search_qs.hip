@@ -214,14 +214,16 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
         issue_piece(std::integral_constant<int, 1>{});
         issue_piece(std::integral_constant<int, 2>{});
         issue_piece(std::integral_constant<int, 3>{});
-        issue_piece(std::integral_constant<int, 4>{});
-        issue_piece(std::integral_constant<int, 5>{});
+        if constexpr (PPS > 4) {
+            issue_piece(std::integral_constant<int, 4>{});
+            issue_piece(std::integral_constant<int, 5>{});
+        }
         if constexpr (PPS > 6) {
             issue_piece(std::integral_constant<int, 6>{});
             issue_piece(std::integral_constant<int, 7>{});
         }
     };
-    static_assert(PPS == 6 || PPS == 8, "pieces per wave per stage");
+    static_assert(PPS == 4 || PPS == 6 || PPS == 8, "pieces per wave per stage");
     static_assert(2 * PPS == G * 4, "one piece after every other k-step");
 
     // the ring is filled first: its HBM latency runs under the loading of Q below
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p)
                         else if (j == 1) issue_piece(std::integral_constant<int, 1>{});
                         else if (j == 3) issue_piece(std::integral_constant<int, 2>{});
                         else if (j == 5) issue_piece(std::integral_constant<int, 3>{});
-                        else if (j == 7) issue_piece(std::integral_constant<int, 4>{});
-                        else if (j == 9) issue_piece(std::integral_constant<int, 5>{});
+                        else if (j == 7 && PPS > 4) issue_piece(std::integral_constant<int, (PPS > 4 ? 4 : 0)>{});
+                        else if (j == 9 && PPS > 4) issue_piece(std::integral_constant<int, (PPS > 4 ? 5 : 0)>{});
                         else if (j == 11 && PPS > 6) issue_piece(std::integral_constant<int, (PPS > 6 ? 6 : 0)>{});
                         else if (j == 13 && PPS > 6) issue_piece(std::integral_constant<int, (PPS > 6 ? 7 : 0)>{});
                     }
@@ -511,14 +513,19 @@ __global__ __launch_bounds__(256) void qs_seed_thr_kernel(const float *__restric
 }
 
 int qs_seed_thresholds(int K, const float *best, int walkers, int n_queries, float *thr0, hipStream_t s) {
-    if (K != 5 || walkers > 256) return MMRAG_EUNSUPPORTED;
-    qs_seed_thr_kernel<5><<<(n_queries + 3) / 4, 256, 0, s>>>(best, walkers, n_queries, thr0);
+    if (walkers > 256) return MMRAG_EUNSUPPORTED;   // (fewer bests than K: the K-th largest is -inf, i.e. no threshold)
+    const unsigned grid = (unsigned)((n_queries + 3) / 4);
+    if (K == 5) qs_seed_thr_kernel<5><<<grid, 256, 0, s>>>(best, walkers, n_queries, thr0);
+    else if (K == 10) qs_seed_thr_kernel<10><<<grid, 256, 0, s>>>(best, walkers, n_queries, thr0);
+    else return MMRAG_EUNSUPPORTED;
     return MMRAG_OK;
 }
 
 bool qs_supported(int dtype, unsigned row_bytes, int K) {
     if (dtype != MMRAG_F16 && dtype != MMRAG_BF16) return false;
-    if (K != 5) return false;
+    // k = 20 was built and measured too: 911 us against 772 for the slab-ring kernel at 1M x 768, B = 256 (the 20-th best
+    // of the sample is a weak threshold, the lists take 80 KB of LDS from the ring and the insertion path spills)
+    if (K != 5 && K != 10) return false;
     const unsigned nk = row_bytes / SLAB;
     return row_bytes % SLAB == 0 && (nk == 6 || nk == 8 || nk == 12);
 }
@@ -548,9 +555,14 @@ int qs_launch(int dtype, int K, const KParams &p, int grid_x, int grid_y, hipStr
     KParams kp = p;
     kp.walkers = grid_x;
     kp.share_l2 = grid_y > 1;
-    if (K != 5) return MMRAG_EUNSUPPORTED;
-    if (dtype == MMRAG_F16) return qs_launch_nk<MMRAG_F16, 5>(kp, grid_x * grid_y, s);
-    if (dtype == MMRAG_BF16) return qs_launch_nk<MMRAG_BF16, 5>(kp, grid_x * grid_y, s);
+    const int grid = grid_x * grid_y;
+    if (dtype == MMRAG_F16) {
+        if (K == 5) return qs_launch_nk<MMRAG_F16, 5>(kp, grid, s);
+        if (K == 10) return qs_launch_nk<MMRAG_F16, 10>(kp, grid, s);
+    } else if (dtype == MMRAG_BF16) {
+        if (K == 5) return qs_launch_nk<MMRAG_BF16, 5>(kp, grid, s);
+        if (K == 10) return qs_launch_nk<MMRAG_BF16, 10>(kp, grid, s);
+    }
     return MMRAG_EUNSUPPORTED;
 }
 
