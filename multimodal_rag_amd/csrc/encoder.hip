@@ -179,14 +179,6 @@ struct LinearParams {
     int act;
     int xcd_order;
     unsigned dbg;
-    // deferred LayerNorm (linear_persistent_kernel only; see "LayerNorm without a LayerNorm pass" below).  `row_stats`
-    // holds (mean, rstd) per token row of an un-normalised tensor and is used for ONE of:
-    //   ln_c != null:      x IS that tensor and wt has the norm's gamma folded in: out = act(rstd (acc - mean c) + bias),
-    //                      bias already holding W.beta;
-    //   res_gamma != null: resid IS that tensor: the row is normalised (gamma, beta) on its way into the add.
-    const float2 *row_stats;
-    const float *ln_c;
-    const float *res_gamma, *res_beta;
 };
 
 template <int BF, int BT, int WF, int WT, int NSTAGE, bool PIPE = false>
@@ -490,8 +482,7 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
     constexpr int STORES = (FT / 2) * TT * 16;
     static_assert(FT % 2 == 0 && PW >= 4, "layout");
     constexpr int STORES_WAIT = STORES < 63 ? STORES : 63;  // vmcnt is a 6-bit counter
-    static_assert(WAVE_T == 64, "one lane per token row of the wave (row statistics)");
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + NW * 512];   // ring + (mean, rstd) of each wave's 64 rows
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -604,10 +595,6 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.0f;
 
-        // deferred LayerNorm: (mean, rstd) of this wave's 64 token rows, one row per lane.  Parked in LDS in the second
-        // iteration, whose wait retires every older operation anyway, and read back row by row in the epilogue
-        float2 stat_v = make_float2(0.f, 1.f);
-        if (p.row_stats != nullptr && t0 + wt_ * WAVE_T + lane < p.M) stat_v = p.row_stats[t0 + wt_ * WAVE_T + lane];
         load(fw[0], fx[0], smem + (g & 1) * STAGE, 0);
         for (int it = 0; it < nk; ++it, ++g) {
             const char *st = smem + (g & 1) * STAGE;
@@ -625,7 +612,6 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
             // stores of the previous tile are YOUNGER than item g+1 and may stay in flight
             if (it == 0 && g != 0) wait_vmcnt<STORES_WAIT>();
             else wait_vmcnt<0>();
-            if (it == 1 && p.row_stats != nullptr) *(float2 *)(smem + 2 * STAGE + wave * 512 + lane * 8) = stat_v;
             __builtin_amdgcn_s_barrier();
             {   // item g+2 goes into the stage every wave has just finished reading
                 const int k2 = it + 2;
@@ -657,99 +643,51 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
         const unsigned wrow_b = (unsigned)(wt_ * WAVE_T) * row_b;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)t0 * p.N, (p.dbg & DBG_LINEAR_DROP_STORES) ? 0u : valid);
         const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.resid != nullptr ? p.resid + (size_t)t0 * p.N : p.out, p.resid != nullptr ? valid : 0u);
-        const bool ln_in = p.ln_c != nullptr, res_ln = p.res_gamma != nullptr;
-        const char *const stat_lds = smem + 2 * STAGE + wave * 512 + 4 * he * 8;
-        auto finish = [&](auto act_tag, auto res_tag, auto ragged_tag, auto norms_tag) {
+        auto finish = [&](auto act_tag, auto res_tag, auto ragged_tag) {
             constexpr int ACT = decltype(act_tag)::value;
             constexpr bool RES = decltype(res_tag)::value;
             constexpr bool RAGGED = decltype(ragged_tag)::value;
-            constexpr bool NORMS = decltype(norms_tag)::value;   // row statistics in play (deferred LayerNorm)
-            constexpr int NB = FT / 2;
-            // per feature block: this lane's feature pair and its per-feature constants
-            unsigned voff[NB];
-            float2 bias2[NB], c2[NB], gam2[NB], bet2[NB];
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                const int fcol = f0 + wf * WAVE_F + blk * 64 + 2 * r32e;
+            for (int blk = 0; blk < FT / 2; ++blk) {
+                const int fcol = f0 + wf * WAVE_F + blk * 64 + 2 * r32e;   // this lane's feature pair
                 const bool f_ok = fcol < p.N;                               // N is even
                 // (an out-of-range pair gets an offset that stays out of range with any row added)
-                voff[blk] = f_ok ? (unsigned)(4 * he) * row_b + (unsigned)fcol * 2u : 0x80000000u;
-                bias2[blk] = make_float2(0.f, 0.f);
-                if (p.bias != nullptr && f_ok) bias2[blk] = *(const float2 *)(p.bias + fcol);
-                if constexpr (NORMS) {
-                    c2[blk] = make_float2(0.f, 0.f);
-                    gam2[blk] = make_float2(1.f, 1.f);
-                    bet2[blk] = make_float2(0.f, 0.f);
-                    if (ln_in && f_ok) c2[blk] = *(const float2 *)(p.ln_c + fcol);
-                    if (res_ln && f_ok) {
-                        gam2[blk] = *(const float2 *)(p.res_gamma + fcol);
-                        bet2[blk] = *(const float2 *)(p.res_beta + fcol);
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < TT; ++b) {
-                unsigned rv[NB][16];
+                const unsigned voff = f_ok ? (unsigned)(4 * he) * row_b + (unsigned)fcol * 2u : 0x80000000u;
+                float2 bias2 = make_float2(0.f, 0.f);
+                if (p.bias != nullptr && f_ok) bias2 = *(const float2 *)(p.bias + fcol);
+                unsigned rv[TT][16];
                 if constexpr (RES) {
 #pragma unroll
-                    for (int blk = 0; blk < NB; ++blk)
+                    for (int b = 0; b < TT; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const unsigned ro = wrow_b + (unsigned)(b * 32 + 8 * (r >> 2) + (r & 3)) * row_b;
-                            rv[blk][r] = RAGGED ? __builtin_amdgcn_raw_buffer_load_b32(rs_res, voff[blk] + ro, 0, 0)
-                                                : __builtin_amdgcn_raw_buffer_load_b32(rs_res, voff[blk], ro, 0);
+                            rv[b][r] = RAGGED ? __builtin_amdgcn_raw_buffer_load_b32(rs_res, voff + ro, 0, 0)
+                                              : __builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, ro, 0);
                         }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lrow = b * 32 + 8 * (r >> 2) + (r & 3);       // row of the wave's 64 (+ 4 for the upper half-wave)
-                    const unsigned ro = wrow_b + (unsigned)lrow * row_b;
-                    float rs_in = 1.f, rmu_in = 0.f, rs_re = 1.f, mu_re = 0.f;
-                    if constexpr (NORMS) {
-                        const float2 st = *(const float2 *)(stat_lds + lrow * 8);
-                        // the unused one of the two roles runs on (mean 0, rstd 1, gamma 1, beta 0, c 0): exact
-                        rs_in = ln_in ? st.y : 1.f, rmu_in = ln_in ? st.y * st.x : 0.f;
-                        rs_re = res_ln ? st.y : 1.f, mu_re = res_ln ? st.x : 0.f;
-                    }
+                for (int b = 0; b < TT; ++b)
 #pragma unroll
-                    for (int blk = 0; blk < NB; ++blk) {
-                        float a0, a1;
-                        if constexpr (NORMS) {
-                            a0 = fmaf(acc[2 * blk][b][r], rs_in, fmaf(-rmu_in, c2[blk].x, bias2[blk].x));
-                            a1 = fmaf(acc[2 * blk + 1][b][r], rs_in, fmaf(-rmu_in, c2[blk].y, bias2[blk].y));
-                        } else {
-                            a0 = acc[2 * blk][b][r] + bias2[blk].x;
-                            a1 = acc[2 * blk + 1][b][r] + bias2[blk].y;
-                        }
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned ro = wrow_b + (unsigned)(b * 32 + 8 * (r >> 2) + (r & 3)) * row_b;
                         // (the activated value is rounded to fp16 before the residual add, as in linear_kernel)
-                        half2_t o = f2h(act_apply<ACT>(a0), act_apply<ACT>(a1));
-                        if constexpr (RES) {
-                            const half2_t y = __builtin_bit_cast(half2_t, rv[blk][r]);
-                            if constexpr (NORMS)   // the normalised row is rounded to fp16 like a LayerNorm pass would have stored it
-                                o = o + f2h(fmaf(((float)y[0] - mu_re) * rs_re, gam2[blk].x, bet2[blk].x),
-                                            fmaf(((float)y[1] - mu_re) * rs_re, gam2[blk].y, bet2[blk].y));
-                            else
-                                o = o + y;
-                        }
+                        half2_t o = f2h(act_apply<ACT>(acc[2 * blk][b][r] + bias2.x), act_apply<ACT>(acc[2 * blk + 1][b][r] + bias2.y));
+                        if constexpr (RES) o = o + __builtin_bit_cast(half2_t, rv[b][r]);
                         if constexpr (RAGGED)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff[blk] + ro, 0, 2);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff + ro, 0, 2);
                         else
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff[blk], ro, 2);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff, ro, 2);
                     }
-                }
             }
-        };
-        auto with_norms = [&](auto act_tag, auto res_tag, auto ragged_tag) {
-            if (p.row_stats != nullptr) finish(act_tag, res_tag, ragged_tag, std::true_type{});
-            else finish(act_tag, res_tag, ragged_tag, std::false_type{});
         };
         auto with_res = [&](auto act_tag) {
             if (rows < BT) {
-                if (p.resid != nullptr) with_norms(act_tag, std::true_type{}, std::true_type{});
-                else with_norms(act_tag, std::false_type{}, std::true_type{});
+                if (p.resid != nullptr) finish(act_tag, std::true_type{}, std::true_type{});
+                else finish(act_tag, std::false_type{}, std::true_type{});
             } else {
-                if (p.resid != nullptr) with_norms(act_tag, std::true_type{}, std::false_type{});
-                else with_norms(act_tag, std::false_type{}, std::false_type{});
+                if (p.resid != nullptr) finish(act_tag, std::true_type{}, std::false_type{});
+                else finish(act_tag, std::false_type{}, std::false_type{});
             }
         };
         if (p.act == MMRAG_ACT_GELU) with_res(std::integral_constant<int, MMRAG_ACT_GELU>{});
@@ -1158,103 +1096,10 @@ __global__ __launch_bounds__(64 * NWC) void linear_small_kernel(const LinearPara
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm without a LayerNorm pass (BERT, post-LN, big batches).
-//
-// A LayerNorm pass reads and writes the whole activation (2 x 100 MB per norm at 65536 x 768: 54 us, twice per layer,
-// at the HBM roofline -- only not running it helps).  With y the un-normalised rows, m / r their mean / rstd and
-// h = (y - m) r gamma + beta:
-//   * a GEMM that consumes h:   h . W^T = r (y . W'^T - m c) + W.beta,  W' = W diag(gamma), c = row sums of W'.
-//     fold_norm_into_weights_kernel makes W', c and bias + W.beta (per forward, into the workspace: 8 MB for bge, 1 % of a
-//     layer); the GEMM runs on y and applies r, m, c in its epilogue;
-//   * the residual add that consumes h normalises the row it loads anyway (gamma, beta per lane, m / r per row);
-//   * the statistics come from row_stats_kernel: one read of y (the LayerNorm kernel's own two-pass arithmetic, so m and r
-//     are the values the pass would have used) and 8 bytes per row out.  Summing y and y^2 in the producing GEMM's
-//     epilogue instead was built and measured: 160 DPP steps per wave and tile cost more than this read.
-// Only the last layer's output meets a real LayerNorm pass (the pooling reads it).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fold_norm_into_weights_kernel(const _Float16 *__restrict__ w, const float *__restrict__ bias,
-                                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                     _Float16 *__restrict__ w_out, float *__restrict__ c_out,
-                                                                     float *__restrict__ bias_out, int N, int K) {
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per output feature
-    const int lane = threadIdx.x & 63;
-    if (f >= N) return;
-    float c = 0.f, d = 0.f;
-    for (int k = lane * 2; k < K; k += 128) {
-        const float2 wv = h2f(*(const half2_t *)(w + (size_t)f * K + k));
-        const float2 g = *(const float2 *)(gamma + k), b = *(const float2 *)(beta + k);
-        const half2_t o = f2h(wv.x * g.x, wv.y * g.y);
-        *(half2_t *)(w_out + (size_t)f * K + k) = o;
-        c += (float)o[0] + (float)o[1];            // of the ROUNDED weights: the ones the GEMM multiplies by
-        d = fmaf(wv.x, b.x, fmaf(wv.y, b.y, d));
-    }
-    c = wave_sum(c);
-    d = wave_sum(d);
-    if (lane == 0) {
-        c_out[f] = c;
-        bias_out[f] = d + (bias != nullptr ? bias[f] : 0.f);
-    }
-}
-
-__global__ __launch_bounds__(256) void row_stats_kernel(const _Float16 *__restrict__ x, float2 *__restrict__ stats, int T, int H,
-                                                        float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per row, H <= 1024
-    if (row >= T) return;
-    const _Float16 *src = x + (size_t)row * H;
-    const int nchunk = H >> 3;
-    float v[2][8];
-    float s_ = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = lane + i * 64;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-        if (c < nchunk) {
-            const half8_t t = ((const half8_t *)src)[c];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[i][e] = (float)t[e];
-                s_ += v[i][e];
-            }
-        }
-    }
-    const float mean = wave_sum(s_) / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (lane + i * 64 < nchunk) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float dx = v[i][e] - mean;
-                q += dx * dx;
-            }
-        }
-    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-    if (lane == 0) stats[row] = make_float2(mean, rstd);
-}
-
-// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-// what the deferred-LayerNorm forward adds to a GEMM call (all optional; LinearParams explains the fields)
-struct LinearNorms {
-    const float2 *row_stats = nullptr;
-    const float *ln_c = nullptr;
-    const float *res_gamma = nullptr, *res_beta = nullptr;
-};
-
-// does (M, N, K) take linear_persistent_kernel, the only GEMM kernel that knows LinearNorms?
-static bool takes_persistent_kernel(long long M, int N, int K) {
-    const unsigned dbg = debug_flags();
-    const long long tiles_f = (N + 255) / 256;
-    const long long big_tiles = ((M + 255) / 256) * tiles_f;
-    return M > 64 && big_tiles >= num_cus() && (double)N >= 0.65 * (double)(tiles_f * 256) && K >= 128 && N % 2 == 0 &&
-           !(dbg & (DBG_LINEAR_PLAIN | DBG_LINEAR_NO_PERSIST));
-}
-
 int launch_linear(const void *x, int M, int K, const void *wt, int N, const float *bias, int act,
-                  const void *resid, void *out, hipStream_t s, const LinearNorms *norms = nullptr) {
+                  const void *resid, void *out, hipStream_t s) {
     LinearParams p;
     p.x = (const char *)x;
     p.wt = (const char *)wt;
@@ -1265,14 +1110,6 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
     const unsigned dbg = debug_flags();
     p.xcd_order = (dbg & DBG_LINEAR_PLAIN) ? 0 : 1;
     p.dbg = dbg;
-    p.row_stats = nullptr, p.ln_c = nullptr, p.res_gamma = nullptr, p.res_beta = nullptr;
-    if (norms != nullptr) {
-        if (!takes_persistent_kernel(M, N, K)) {
-            set_error("linear: deferred LayerNorm needs the persistent kernel (M=%d N=%d K=%d)", M, N, K);
-            return MMRAG_EUNSUPPORTED;
-        }
-        p.row_stats = norms->row_stats, p.ln_c = norms->ln_c, p.res_gamma = norms->res_gamma, p.res_beta = norms->res_beta;
-    }
     if (M <= 64 && (K / 4) % 16 == 0 && !(dbg & DBG_LINEAR_NO_SMALL)) {
         // the online single-query path: split-K over the 16 / 8 / 4 waves of a 32-feature workgroup
         const unsigned g = (unsigned)((N + 31) / 32);
@@ -1407,19 +1244,11 @@ size_t mmrag_encoder_workspace_bytes(const mmrag_encoder_desc *d, int64_t T, int
     bytes += align256((size_t)T * H * 2);          // ctx
     bytes += align256(hm_elems(d, T, B) * 2);      // mlp hidden (also holds the ViT patch rows)
     bytes += 2 * align256((size_t)B * (H > (size_t)d->out_dim ? H : (size_t)d->out_dim) * 2);  // pooled, projected
-    if (d->arch == MMRAG_ARCH_BERT) {   // deferred LayerNorm: folded weights of one GEMM, row statistics
-        const size_t nf = 3 * H > I ? 3 * H : I;
-        bytes += align256(nf * H * 2) + 2 * align256(nf * 4);
-        bytes += 2 * align256((size_t)T * 8);
-    }
     return bytes + 256;
 }
 
 struct EncBuffers {
     void *x, *y, *qkv, *ctx, *hm, *pooled, *proj;
-    void *w_fold;                         // BERT only (deferred LayerNorm)
-    float *c_fold, *b_fold;
-    float2 *stats_a, *stats_b;
 };
 
 static int carve(const mmrag_encoder_desc *d, int64_t T, int B, void *workspace, size_t workspace_bytes,
@@ -1436,13 +1265,6 @@ static int carve(const mmrag_encoder_desc *d, int64_t T, int B, void *workspace,
     b->hm = take(hm_elems(d, T, B) * 2);
     const size_t pd = (size_t)(d->hidden > d->out_dim ? d->hidden : d->out_dim);
     b->pooled = take((size_t)B * pd * 2), b->proj = take((size_t)B * pd * 2);
-    b->w_fold = nullptr;
-    if (d->arch == MMRAG_ARCH_BERT) {
-        const size_t I = (size_t)d->intermediate, nf = 3 * H > I ? 3 * H : I;
-        b->w_fold = take(nf * H * 2);
-        b->c_fold = (float *)take(nf * 4), b->b_fold = (float *)take(nf * 4);
-        b->stats_a = (float2 *)take(Tz * 8), b->stats_b = (float2 *)take(Tz * 8);
-    }
     return MMRAG_OK;
 }
 
@@ -1456,46 +1278,6 @@ static int encoder_body(const mmrag_encoder_desc *d, const void *const *lw, cons
     void *x = b.x, *y = b.y, *qkv = b.qkv, *ctx = b.ctx, *hm = b.hm;
     int st;
     const int causal = d->causal;
-    hipStream_t s = (hipStream_t)stream;
-    const bool deferred_ln = d->arch == MMRAG_ARCH_BERT && b.w_fold != nullptr && !(debug_flags() & DBG_ENCODER_LN_PASSES) &&
-                             takes_persistent_kernel(T, 3 * H, H) && takes_persistent_kernel(T, H, H) &&
-                             takes_persistent_kernel(T, I, H) && takes_persistent_kernel(T, H, I);
-    if (deferred_ln) {
-        // see "LayerNorm without a LayerNorm pass": x and y alternate as the un-normalised outputs of FFN2 / O-proj
-        const unsigned stat_grid = (unsigned)((T + 3) / 4);
-        auto fold = [&](const void *w, const float *bias, const float *gamma, const float *beta, int N) {
-            fold_norm_into_weights_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(
-                (const _Float16 *)w, bias, gamma, beta, (_Float16 *)b.w_fold, b.c_fold, b.b_fold, N, H);
-        };
-        const float *g_prev = nullptr, *b_prev = nullptr;   // the previous layer's output norm (none before layer 0)
-        for (int l = 0; l < L; ++l, lw += 12) {
-            const float *bqkv = (const float *)lw[1], *bo = (const float *)lw[3];
-            const float *g1 = (const float *)lw[4], *b1n = (const float *)lw[5];
-            const float *bi = (const float *)lw[7], *b2 = (const float *)lw[9];
-            LinearNorms nq, no, n1, n2;
-            if (l == 0) {
-                RUN(launch_linear(x, (int)T, H, lw[0], 3 * H, bqkv, MMRAG_ACT_NONE, nullptr, qkv, s));
-            } else {
-                fold(lw[0], bqkv, g_prev, b_prev, 3 * H);
-                nq.row_stats = b.stats_b, nq.ln_c = b.c_fold;
-                RUN(launch_linear(x, (int)T, H, b.w_fold, 3 * H, b.b_fold, MMRAG_ACT_NONE, nullptr, qkv, s, &nq));
-                no.row_stats = b.stats_b, no.res_gamma = g_prev, no.res_beta = b_prev;
-            }
-            RUN(mmrag_attention_f16(qkv, cu_seqlens, ctx, B, max_len, H, d->n_heads, causal, stream));
-            RUN(launch_linear(ctx, (int)T, H, lw[2], H, bo, MMRAG_ACT_NONE, x, y, s, &no));
-            row_stats_kernel<<<stat_grid, 256, 0, s>>>((const _Float16 *)y, b.stats_a, (int)T, H, d->ln_eps);
-            fold(lw[6], bi, g1, b1n, I);
-            n1.row_stats = b.stats_a, n1.ln_c = b.c_fold;
-            RUN(launch_linear(y, (int)T, H, b.w_fold, I, b.b_fold, d->act, nullptr, hm, s, &n1));
-            n2.row_stats = b.stats_a, n2.res_gamma = g1, n2.res_beta = b1n;
-            RUN(launch_linear(hm, (int)T, I, lw[8], H, b2, MMRAG_ACT_NONE, y, x, s, &n2));
-            if (l + 1 < L) row_stats_kernel<<<stat_grid, 256, 0, s>>>((const _Float16 *)x, b.stats_b, (int)T, H, d->ln_eps);
-            g_prev = (const float *)lw[10], b_prev = (const float *)lw[11];
-        }
-        MMRAG_CHECK_HIP(hipGetLastError());
-        RUN(mmrag_layernorm_f16(x, y, g_prev, b_prev, T, H, d->ln_eps, stream));   // the pooling reads real rows
-        return mmrag_pool_normalize_f16(y, cu_seqlens, sel, out, B, H, d->pool, d->normalize, stream);
-    }
     for (int l = 0; l < L; ++l, lw += 12) {
         const float *bqkv = (const float *)lw[1], *bo = (const float *)lw[3];
         const float *g1 = (const float *)lw[4], *b1n = (const float *)lw[5];
@@ -1519,6 +1301,7 @@ static int encoder_body(const mmrag_encoder_desc *d, const void *const *lw, cons
             RUN(mmrag_linear_f16(hm, T, I, lw[8], H, b2, MMRAG_ACT_NONE, x, x, stream));
         }
     }
+    hipStream_t s = (hipStream_t)stream;
     if (d->arch == MMRAG_ARCH_BERT) {
         RUN(mmrag_pool_normalize_f16(x, cu_seqlens, sel, out, B, H, d->pool, d->normalize, stream));
     } else {

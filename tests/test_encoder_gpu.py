@@ -202,42 +202,3 @@ def test_full_forward_vs_oracle_and_transformers_golden(N, golden_dir, name, sha
     assert err <= 4e-3 and cos >= 0.9999, (float(err), float(cos))
     # and the fp16 device result stays close to the float32 transformers output
     assert (got * golden).sum(1).min() >= 0.999
-
-
-@pytest.mark.parametrize("hidden,heads,inter,n_seq,max_len", [(768, 12, 3072, 140, 256), (384, 12, 1536, 300, 200)])
-def test_deferred_layernorm_equals_layernorm_passes(N, hidden, heads, inter, n_seq, max_len):
-    """Big batches run BERT without LayerNorm passes (csrc/encoder.hip "LayerNorm without a LayerNorm pass": statistics
-    from the producing GEMM's epilogue, gamma folded into the consuming GEMM's weights, the residual normalised on load).
-    Same embeddings as the forward WITH the passes (which the oracle tests pin), ragged sequence lengths, non-trivial
-    gamma / beta."""
-    import ctypes
-
-    from multimodal_rag_amd.encoder import DeviceEncoder, EncoderConfig, random_bert_weights
-
-    cfg = EncoderConfig("t", 3, hidden, heads, inter, vocab=2000, max_pos=256, max_seq_length=256, pool="mean")
-    w = random_bert_weights(cfg, seed=9, device="cuda:0", std=0.05)
-    g = torch.Generator(device="cuda:0").manual_seed(3)
-    for k in list(w):
-        if "LayerNorm.weight" in k:
-            w[k] = 1.0 + 0.3 * torch.randn(w[k].shape, device="cuda:0", generator=g)
-        elif "LayerNorm.bias" in k:
-            w[k] = 0.2 * torch.randn(w[k].shape, device="cuda:0", generator=g)
-    enc = DeviceEncoder(cfg, w, "cuda:0")
-    rng = np.random.default_rng(4)
-    lens = rng.integers(max_len // 2, max_len + 1, n_seq)
-    seqs = [rng.integers(5, 2000, int(n)).tolist() for n in lens]
-    assert (sum(lens) // 256) * ((hidden + 255) // 256) >= 256   # enough 256-row tiles for the persistent GEMM on every shape
-    L = N.lib()
-    L.mmrag_internal_set_debug.argtypes = [ctypes.c_uint]
-    try:
-        L.mmrag_internal_set_debug(512)          # DBG_ENCODER_LN_PASSES
-        ref = enc.encode_ids(seqs).cpu().numpy()
-        L.mmrag_internal_set_debug(0)
-        got = enc.encode_ids(seqs).cpu().numpy()
-        again = enc.encode_ids(seqs).cpu().numpy()
-    finally:
-        L.mmrag_internal_set_debug(0)
-    assert np.array_equal(got, again)            # no atomics: bit-reproducible
-    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-3
-    assert np.abs(got - ref).max() <= 2e-3, float(np.abs(got - ref).max())
-    assert float(np.min(np.sum(got * ref, axis=1))) > 0.9999
