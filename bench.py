@@ -340,6 +340,7 @@ def main():
                     traffic_source = f"profiles/traffic.json ({t.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}; not measured by this run)"
             except Exception:
                 pass
+        uses_qs = N.search_uses_query_stationary(B, n_local, DIM, k, dtype)
         dev_info = N.device_info()
         peaks = {}
         if not args.no_peaks:
@@ -369,10 +370,12 @@ def main():
                 "parallelism": f"row-shard x{world}", "result_rows_md5": rows_md5,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "cosine_topk_qs_kernel",
-                "launch": "one scan = sample pass (first 65536 rows, best score per query per workgroup) + "
-                          "qs_seed_thr_kernel + the walk over all rows, all cosine_topk_qs_kernel; timed with HIP events "
-                          "around the three launches of every step",
+                "bound": "hbm", "kernel": "cosine_topk_qs_kernel" if uses_qs else "cosine_topk_kernel (slab-ring)",
+                "launch": ("one scan = sample pass (first 65536 rows, best score per query per workgroup) + "
+                           "qs_seed_thr_kernel + the walk over all rows, all cosine_topk_qs_kernel; timed with HIP events "
+                           "around the three launches of every step") if uses_qs else
+                          ("one scan = the launches of mmrag_cosine_topk_lists for this shard (sample pre-pass + merge "
+                           "where the shard is long enough, then the main pass); timed with HIP events around them"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": round(kern_ms, 4),

@@ -44,6 +44,8 @@ def _declare(lib):
     lib.mmrag_cosine_topk_lists.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int, c_int,
                                             c_void_p, c_void_p, c_size_t, c_void_p]
     # debug form of mmrag_cosine_topk_lists (kernel-shape switches; csrc/search.hip, not in include/mmrag.h)
+    lib.mmrag_internal_search_uses_qs.restype = c_int
+    lib.mmrag_internal_search_uses_qs.argtypes = [c_int, c_int64, c_int64, c_int, c_int]
     lib.mmrag_internal_cosine_topk_lists_ex.restype = c_int
     lib.mmrag_internal_cosine_topk_lists_ex.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int,
                                                         c_int, c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_uint]
@@ -135,6 +137,11 @@ def _dev_check(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise MMRagNativeError("libmmrag entry points take device (HIP) tensors only; got a CPU tensor")
+
+
+def search_uses_query_stationary(B: int, n: int, d: int, k: int, dtype: torch.dtype) -> bool:
+    """which kernel a search of this shape runs on (True: cosine_topk_qs_kernel, False: the slab-ring cosine_topk_kernel)"""
+    return bool(lib().mmrag_internal_search_uses_qs(B, n, padded_dim(d, dtype), _TORCH2DT[dtype], k))
 
 
 def padded_dim(d: int, dtype: torch.dtype) -> int:

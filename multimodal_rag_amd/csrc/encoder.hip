@@ -1095,6 +1095,72 @@ __global__ __launch_bounds__(64 * NWC) void linear_small_kernel(const LinearPara
 #endif
 }
 
+// M <= 64, second form: 16 features per workgroup (v_mfma_f32_16x16x32_f16), i.e. twice the workgroups of
+// linear_small_kernel.  One query is 3-30 token rows against N = 384-3072 features: N / 32 workgroups leave most of the
+// 256 CUs idle and each busy CU streams its weight rows alone (4.9 us at K = 384, 9.2 us at K = 1536, rocprof).
+// NWC waves split K in shares of 32 * STEPS; every wave has all its loads in flight at once; wave 0 reduces.
+template <int NWC, int STEPS>
+__global__ __launch_bounds__(64 * NWC) void linear_small16_kernel(const LinearParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float part[NWC][4][64];  // [wave][register][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int f0 = blockIdx.x * 16;
+    const int k_lo = wave * (32 * STEPS);
+    const int fr = f0 + r16 < p.N ? f0 + r16 : p.N - 1;   // clamped: out-of-range rows are computed and dropped
+    const _Float16 *wrow = (const _Float16 *)p.wt + (size_t)fr * p.K + k_lo + 8 * kq;
+    half8_t a[STEPS];
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; ++s_) a[s_] = *(const half8_t *)(wrow + 32 * s_);
+    for (int t0 = 0; t0 < p.M; t0 += 16) {
+        const int tr = t0 + r16 < p.M ? t0 + r16 : p.M - 1;
+        const _Float16 *xrow = (const _Float16 *)p.x + (size_t)tr * p.K + k_lo + 8 * kq;
+        half8_t b[STEPS];
+#pragma unroll
+        for (int s_ = 0; s_ < STEPS; ++s_) b[s_] = *(const half8_t *)(xrow + 32 * s_);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < STEPS; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s_], b[s_], acc, 0, 0, 0);
+        if (t0 > 0) __syncthreads();  // the previous token block's partials have been consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[wave][j][lane] = acc[j];
+        __syncthreads();
+        // wave 0: lane (token r16, feature group kq) owns features f0 + 4 kq + (0..3) of token t0 + r16
+        const int t = t0 + r16;
+        const int f = f0 + 4 * kq;
+        if (wave == 0 && t < p.M && f < p.N) {   // N % 4 == 0: a group of four features is in range together
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NWC; ++w)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += part[w][i][lane];
+            if (p.bias != nullptr) {
+                const float4 bv = *(const float4 *)(p.bias + f);
+                v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
+            }
+            half4_t o;
+            if (p.act == MMRAG_ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply<MMRAG_ACT_GELU>(v[i]);
+            } else if (p.act == MMRAG_ACT_QUICK_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)act_apply<MMRAG_ACT_QUICK_GELU>(v[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
+            }
+            if (p.resid != nullptr) {
+                const half4_t rv = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)((float)o[i] + (float)rv[i]);
+            }
+            *(half4_t *)(p.out + (size_t)t * p.N + f) = o;
+        }
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -1110,8 +1176,22 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
     const unsigned dbg = debug_flags();
     p.xcd_order = (dbg & DBG_LINEAR_PLAIN) ? 0 : 1;
     p.dbg = dbg;
+    if (M <= 64 && !(dbg & (DBG_LINEAR_NO_SMALL | DBG_LINEAR_SMALL32))) {
+        // the online single-query path, 16 features per workgroup: K in shares of 32 * STEPS over up to 16 waves
+        const unsigned g16 = (unsigned)((N + 15) / 16);
+        bool done = true;
+        if (K == 384) linear_small16_kernel<12, 1><<<g16, 768, 0, s>>>(p);
+        else if (K == 512) linear_small16_kernel<16, 1><<<g16, 1024, 0, s>>>(p);
+        else if (K == 768) linear_small16_kernel<12, 2><<<g16, 768, 0, s>>>(p);
+        else if (K == 1024) linear_small16_kernel<16, 2><<<g16, 1024, 0, s>>>(p);
+        else if (K == 1536) linear_small16_kernel<16, 3><<<g16, 1024, 0, s>>>(p);
+        else if (K == 2048) linear_small16_kernel<16, 4><<<g16, 1024, 0, s>>>(p);
+        else if (K == 3072) linear_small16_kernel<16, 6><<<g16, 1024, 0, s>>>(p);
+        else done = false;
+        if (done) return MMRAG_OK;
+    }
     if (M <= 64 && (K / 4) % 16 == 0 && !(dbg & DBG_LINEAR_NO_SMALL)) {
-        // the online single-query path: split-K over the 16 / 8 / 4 waves of a 32-feature workgroup
+        // other K: split-K over the 16 / 8 / 4 waves of a 32-feature workgroup
         const unsigned g = (unsigned)((N + 31) / 32);
         if (K % 256 == 0) linear_small_kernel<16><<<g, 1024, 0, s>>>(p);
         else if (K % 128 == 0) linear_small_kernel<8><<<g, 512, 0, s>>>(p);

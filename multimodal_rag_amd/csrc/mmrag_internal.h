@@ -38,6 +38,7 @@ unsigned debug_flags();
 constexpr unsigned DBG_LINEAR_PLAIN = 1u, DBG_LINEAR_NO_SMALL = 2u, DBG_LINEAR_NO_PERSIST = 4u;
 // timing-only ablations of the persistent linear kernel (results are wrong): stores dropped by the buffer unit, no epilogue at all
 constexpr unsigned DBG_LINEAR_DROP_STORES = 8u, DBG_LINEAR_SKIP_EPILOGUE = 16u;
-constexpr unsigned DBG_LINEAR_X_SAME = 128u;   // timing only: every tile reads the first token tile
+constexpr unsigned DBG_LINEAR_X_SAME = 128u;
+constexpr unsigned DBG_LINEAR_SMALL32 = 256u;   // M <= 64: the 32-feature workgroups for every K (A/B)   // timing only: every tile reads the first token tile
 
 }  // namespace mmrag

@@ -762,6 +762,14 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
     return MMRAG_OK;
 }
 
+// which kernel a (B, n, ld, dtype, k) search runs on: 1 = query-stationary (search_qs.hip), 0 = slab-ring.  For the
+// bench's roofline label and the tools; not part of the public ABI.
+int mmrag_internal_search_uses_qs(int B, int64_t n, int64_t ld, int dtype, int k) {
+    if (B <= 0 || n <= 0 || k <= 0 || k > MMRAG_MAX_K) return 0;
+    const Plan pl = make_plan(B, n, k, 0u);
+    return pl.qs_ok && qs_supported(dtype, (unsigned)(ld * esize(dtype)), pl.K) ? 1 : 0;
+}
+
 int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,
                             int k, const uint32_t *alive_bits, void *workspace, size_t workspace_bytes,
                             void *stream) {

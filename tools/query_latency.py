@@ -5,6 +5,10 @@ import numpy as np, torch
 from multimodal_rag_amd.embedder import EmbeddingManager
 
 async def main():
+    if os.environ.get("MMRAG_DEBUG"):   # developer switches of the library (csrc/mmrag_internal.h), e.g. 256 = 32-feature small-M GEMM
+        import ctypes
+        from multimodal_rag_amd import _native
+        _native.lib().mmrag_internal_set_debug(ctypes.c_uint(int(os.environ["MMRAG_DEBUG"])))
     m = EmbeddingManager(batch_size=32, enable_cache=False)
     await m.initialize()
     n = int(os.environ.get("ROWS", "100000"))
