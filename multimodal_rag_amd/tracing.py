@@ -6,7 +6,7 @@ building), and in the sharded service broadcast / exchange / merge -- runs insid
 
   * always: wall-clock seconds, call count and maximum per stage (`snapshot()`, shown by
     `EmbeddingManager.get_collection_stats()["stages"]`; `reset()` clears them);
-  * with `MMRAG_ROCTX=1` in the environment: a roctx range of the same name (libroctx64), so that
+  * with `MMRAG_ROCTX=1` in the environment: a roctx range of the same name (librocprofiler-sdk-roctx), so that
     `rocprofv3 --marker-trace --kernel-trace -- python ...` shows which kernels belong to which stage.
 
 Host-side bookkeeping only: no device synchronisation is added, so a stage that merely enqueues kernels ("search")
@@ -34,7 +34,9 @@ def _load_roctx():
     _roctx_tried = True
     if os.environ.get("MMRAG_ROCTX", "0").lower() not in ("1", "true", "yes"):
         return None
-    for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+    # rocprofv3 records the rocprofiler-sdk flavour of ROCTx; the roctracer one (libroctx64) serves older profilers
+    for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so",
+                 "/opt/rocm/lib/libroctx64.so"):
         try:
             lib = ctypes.CDLL(name)
             lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
