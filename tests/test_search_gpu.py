@@ -252,23 +252,24 @@ def test_query_stationary_parity(N, dtype, B, n, d):
 
 
 @pytest.mark.parametrize("k", [10, 20])
-@pytest.mark.parametrize("B,n,d", [(256, 70_001, 768), (300, 131_123, 384), (129, 300_000, 512)])
-def test_query_stationary_deeper_lists(N, k, B, n, d):
+@pytest.mark.parametrize("B,n,d,dtype", [(256, 70_001, 768, torch.float16), (300, 131_123, 384, torch.float16),
+                                         (129, 300_000, 512, torch.float16), (600, 90_000, 768, torch.bfloat16)])
+def test_query_stationary_deeper_lists(N, k, B, n, d, dtype):
     """k = 10 runs on the query-stationary kernel too (lists of that depth in LDS, a ring that gives up stages for them);
     k = 20 (api.py:163 caps top_k at 20) stays on the slab-ring kernel, DBG_FORCE_QS or not: same checks for both, with
     and without the sample pass, bit for bit between the kernels"""
     q = unit_rows(B, d, 61)
     c = unit_rows(n, d, 62)
-    s, r, es, er = run(N, q, c, k, torch.float16, dbg=N.DBG_FORCE_QS)
+    s, r, es, er = run(N, q, c, k, dtype, dbg=N.DBG_FORCE_QS)
     check(s, r, es, er)
-    qd, _ = to_dev(N, q, torch.float16)
-    cd, _ = to_dev(N, c, torch.float16)
+    qd, _ = to_dev(N, q, dtype)
+    cd, _ = to_dev(N, c, dtype)
     for dbg in (N.DBG_NO_QS, N.DBG_FORCE_QS | N.DBG_NO_PREPASS, 0):
         s2, r2 = N.cosine_topk(qd, cd, n, d, k, dbg=dbg)
         assert np.array_equal(r2.cpu().numpy(), r) and np.array_equal(s2.cpu().numpy(), s), dbg
     g = np.random.default_rng(63)
     alive = g.random(n) < 0.3
-    check(*run(N, q, c, k, torch.float16, row_offset=123_456, alive=alive, dbg=N.DBG_FORCE_QS))
+    check(*run(N, q, c, k, dtype, row_offset=123_456, alive=alive, dbg=N.DBG_FORCE_QS))
 
 
 def test_query_stationary_exact_integers_and_ties(N):
