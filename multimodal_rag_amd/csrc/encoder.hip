@@ -179,6 +179,16 @@ struct LinearParams {
     int act;
     int xcd_order;
     unsigned dbg;
+    // LayerNorm folded into the single-query GEMMs (linear_small16_kernel only; "the single-query path without LayerNorm
+    // launches" below).  ln_gamma != null: x holds UN-normalised rows; the kernel normalises them (gamma, beta, ln_eps) as
+    // it loads them and workgroup 0 leaves (mean, rstd) per row in ln_stats_out.  res_stats != null: resid holds
+    // un-normalised rows whose (mean, rstd) are in res_stats; they are normalised (res_gamma, res_beta) on their way
+    // into the add.
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
+    float2 *ln_stats_out;
+    const float2 *res_stats;
+    const float *res_gamma, *res_beta;
 };
 
 template <int BF, int BT, int WF, int WT, int NSTAGE, bool PIPE = false>
@@ -1099,10 +1109,11 @@ __global__ __launch_bounds__(64 * NWC) void linear_small_kernel(const LinearPara
 // linear_small_kernel.  One query is 3-30 token rows against N = 384-3072 features: N / 32 workgroups leave most of the
 // 256 CUs idle and each busy CU streams its weight rows alone (4.9 us at K = 384, 9.2 us at K = 1536, rocprof).
 // NWC waves split K in shares of 32 * STEPS; every wave has all its loads in flight at once; wave 0 reduces.
-template <int NWC, int STEPS>
+template <int NWC, int STEPS, bool LN_IN = false>
 __global__ __launch_bounds__(64 * NWC) void linear_small16_kernel(const LinearParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ float part[NWC][4][64];  // [wave][register][lane]
+    __shared__ float2 rowsum[NWC][16];  // LN_IN: (sum, sum of squares) of each wave's share of the 16 token rows
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -1113,12 +1124,57 @@ __global__ __launch_bounds__(64 * NWC) void linear_small16_kernel(const LinearPa
     half8_t a[STEPS];
 #pragma unroll
     for (int s_ = 0; s_ < STEPS; ++s_) a[s_] = *(const half8_t *)(wrow + 32 * s_);
+    float gam[LN_IN ? STEPS : 1][8], bet[LN_IN ? STEPS : 1][8];
+    if constexpr (LN_IN) {
+#pragma unroll
+        for (int s_ = 0; s_ < STEPS; ++s_) {
+            const int k = k_lo + 32 * s_ + 8 * kq;
+            const f32x4_t g0 = *(const f32x4_t *)(p.ln_gamma + k), g1 = *(const f32x4_t *)(p.ln_gamma + k + 4);
+            const f32x4_t b0 = *(const f32x4_t *)(p.ln_beta + k), b1 = *(const f32x4_t *)(p.ln_beta + k + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gam[s_][e] = g0[e], gam[s_][4 + e] = g1[e], bet[s_][e] = b0[e], bet[s_][4 + e] = b1[e];
+        }
+    }
     for (int t0 = 0; t0 < p.M; t0 += 16) {
         const int tr = t0 + r16 < p.M ? t0 + r16 : p.M - 1;
         const _Float16 *xrow = (const _Float16 *)p.x + (size_t)tr * p.K + k_lo + 8 * kq;
         half8_t b[STEPS];
 #pragma unroll
         for (int s_ = 0; s_ < STEPS; ++s_) b[s_] = *(const half8_t *)(xrow + 32 * s_);
+        if constexpr (LN_IN) {
+            // the workgroup's waves hold the 16 token rows between them (wave = K share, lane group kq = 8 of every 32):
+            // row sums over the lane's values, over the four lane groups, over the waves (LDS), then normalise in place,
+            // rounding to fp16 as the LayerNorm pass would have stored the row
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < STEPS; ++s_)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)b[s_][e];
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                }
+            s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+            if (t0 > 0) __syncthreads();   // rowsum of the previous token block has been read
+            if (kq == 0) rowsum[wave][r16] = make_float2(s1, s2);
+            __syncthreads();
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWC; ++w) {
+                const float2 v = rowsum[w][r16];
+                t1 += v.x, t2 += v.y;
+            }
+            const float inv_k = 1.0f / (float)p.K, mean = t1 * inv_k;
+            const float rstd = rsqrtf(fmaxf(fmaf(t2, inv_k, -mean * mean), 0.f) + p.ln_eps);
+            if (blockIdx.x == 0 && wave == 0 && kq == 0 && t0 + r16 < p.M && p.ln_stats_out != nullptr)
+                p.ln_stats_out[t0 + r16] = make_float2(mean, rstd);
+#pragma unroll
+            for (int s_ = 0; s_ < STEPS; ++s_)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    b[s_][e] = (_Float16)fmaf(((float)b[s_][e] - mean) * rstd, gam[s_][e], bet[s_][e]);
+        }
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s_ = 0; s_ < STEPS; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s_], b[s_], acc, 0, 0, 0);
@@ -1151,7 +1207,15 @@ __global__ __launch_bounds__(64 * NWC) void linear_small16_kernel(const LinearPa
                 for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
             }
             if (p.resid != nullptr) {
-                const half4_t rv = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+                half4_t rv = *(const half4_t *)(p.resid + (size_t)t * p.N + f);
+                if (p.res_stats != nullptr) {   // un-normalised residual rows: normalise, round as the pass would have
+                    const float2 st = p.res_stats[t];
+                    const float4 g = *(const float4 *)(p.res_gamma + f), be = *(const float4 *)(p.res_beta + f);
+                    rv[0] = (_Float16)fmaf(((float)rv[0] - st.x) * st.y, g.x, be.x);
+                    rv[1] = (_Float16)fmaf(((float)rv[1] - st.x) * st.y, g.y, be.y);
+                    rv[2] = (_Float16)fmaf(((float)rv[2] - st.x) * st.y, g.z, be.z);
+                    rv[3] = (_Float16)fmaf(((float)rv[3] - st.x) * st.y, g.w, be.w);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (_Float16)((float)o[i] + (float)rv[i]);
             }
@@ -1164,9 +1228,35 @@ __global__ __launch_bounds__(64 * NWC) void linear_small16_kernel(const LinearPa
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// what the single-query forward adds to a GEMM call (LinearParams explains the fields)
+struct SmallNorms {
+    const float *ln_gamma = nullptr, *ln_beta = nullptr;
+    float ln_eps = 0.f;
+    float2 *ln_stats_out = nullptr;
+    const float2 *res_stats = nullptr;
+    const float *res_gamma = nullptr, *res_beta = nullptr;
+};
+
+// does (M, K) take linear_small16_kernel, and can that kernel normalise its input rows (K = 32 or 64 per wave)?
+static bool takes_small16_kernel(long long M, int K, bool ln_in) {
+    if (M > 64 || (debug_flags() & (DBG_LINEAR_NO_SMALL | DBG_LINEAR_SMALL32))) return false;
+    if (ln_in) return K == 384 || K == 512 || K == 768 || K == 1024;
+    return K == 384 || K == 512 || K == 768 || K == 1024 || K == 1536 || K == 2048 || K == 3072;
+}
+
 int launch_linear(const void *x, int M, int K, const void *wt, int N, const float *bias, int act,
-                  const void *resid, void *out, hipStream_t s) {
+                  const void *resid, void *out, hipStream_t s, const SmallNorms *norms = nullptr) {
     LinearParams p;
+    p.ln_gamma = p.ln_beta = nullptr, p.ln_eps = 0.f, p.ln_stats_out = nullptr;
+    p.res_stats = nullptr, p.res_gamma = p.res_beta = nullptr;
+    if (norms != nullptr) {
+        if (!takes_small16_kernel(M, K, norms->ln_gamma != nullptr)) {
+            set_error("linear: folded LayerNorm needs the 16-feature single-query kernel (M=%d K=%d)", M, K);
+            return MMRAG_EUNSUPPORTED;
+        }
+        p.ln_gamma = norms->ln_gamma, p.ln_beta = norms->ln_beta, p.ln_eps = norms->ln_eps, p.ln_stats_out = norms->ln_stats_out;
+        p.res_stats = norms->res_stats, p.res_gamma = norms->res_gamma, p.res_beta = norms->res_beta;
+    }
     p.x = (const char *)x;
     p.wt = (const char *)wt;
     p.bias = bias;
@@ -1180,7 +1270,12 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
         // the online single-query path, 16 features per workgroup: K in shares of 32 * STEPS over up to 16 waves
         const unsigned g16 = (unsigned)((N + 15) / 16);
         bool done = true;
-        if (K == 384) linear_small16_kernel<12, 1><<<g16, 768, 0, s>>>(p);
+        if (p.ln_gamma != nullptr) {
+            if (K == 384) linear_small16_kernel<12, 1, true><<<g16, 768, 0, s>>>(p);
+            else if (K == 512) linear_small16_kernel<16, 1, true><<<g16, 1024, 0, s>>>(p);
+            else if (K == 768) linear_small16_kernel<12, 2, true><<<g16, 768, 0, s>>>(p);
+            else linear_small16_kernel<16, 2, true><<<g16, 1024, 0, s>>>(p);   // K == 1024
+        } else if (K == 384) linear_small16_kernel<12, 1><<<g16, 768, 0, s>>>(p);
         else if (K == 512) linear_small16_kernel<16, 1><<<g16, 1024, 0, s>>>(p);
         else if (K == 768) linear_small16_kernel<12, 2><<<g16, 768, 0, s>>>(p);
         else if (K == 1024) linear_small16_kernel<16, 2><<<g16, 1024, 0, s>>>(p);
@@ -1324,11 +1419,13 @@ size_t mmrag_encoder_workspace_bytes(const mmrag_encoder_desc *d, int64_t T, int
     bytes += align256((size_t)T * H * 2);          // ctx
     bytes += align256(hm_elems(d, T, B) * 2);      // mlp hidden (also holds the ViT patch rows)
     bytes += 2 * align256((size_t)B * (H > (size_t)d->out_dim ? H : (size_t)d->out_dim) * 2);  // pooled, projected
+    bytes += 2 * align256(64 * 8);                 // (mean, rstd) of up to 64 rows, twice (single-query path)
     return bytes + 256;
 }
 
 struct EncBuffers {
     void *x, *y, *qkv, *ctx, *hm, *pooled, *proj;
+    float2 *stats_a, *stats_b;
 };
 
 static int carve(const mmrag_encoder_desc *d, int64_t T, int B, void *workspace, size_t workspace_bytes,
@@ -1345,6 +1442,7 @@ static int carve(const mmrag_encoder_desc *d, int64_t T, int B, void *workspace,
     b->hm = take(hm_elems(d, T, B) * 2);
     const size_t pd = (size_t)(d->hidden > d->out_dim ? d->hidden : d->out_dim);
     b->pooled = take((size_t)B * pd * 2), b->proj = take((size_t)B * pd * 2);
+    b->stats_a = (float2 *)take(64 * 8), b->stats_b = (float2 *)take(64 * 8);
     return MMRAG_OK;
 }
 
@@ -1358,6 +1456,38 @@ static int encoder_body(const mmrag_encoder_desc *d, const void *const *lw, cons
     void *x = b.x, *y = b.y, *qkv = b.qkv, *ctx = b.ctx, *hm = b.hm;
     int st;
     const int causal = d->causal;
+    hipStream_t s = (hipStream_t)stream;
+    // The single-query path without LayerNorm launches (BERT, T <= 64): a query is a chain of ~45 dependent kernels of
+    // 3-5 us, 12 of them LayerNorms over a few rows.  Here the GEMM that consumes a normalised tensor normalises the rows
+    // itself as it loads them (its workgroup holds whole rows between its waves) and leaves (mean, rstd) behind for the
+    // residual add two kernels later, which normalises the rows it adds.  x and y alternate as the UN-normalised outputs
+    // of FFN2 / O-proj; only the last layer's output meets a real LayerNorm (the pooling reads it).
+    const bool folded_ln = d->arch == MMRAG_ARCH_BERT && !(debug_flags() & DBG_ENCODER_LN_PASSES) &&
+                           takes_small16_kernel(T, H, true) && takes_small16_kernel(T, I, false);
+    if (folded_ln) {
+        const float *g_prev = nullptr, *b_prev = nullptr;   // the previous layer's output norm (none before layer 0)
+        for (int l = 0; l < L; ++l, lw += 12) {
+            const float *bqkv = (const float *)lw[1], *bo = (const float *)lw[3];
+            const float *g1 = (const float *)lw[4], *b1n = (const float *)lw[5];
+            const float *bi = (const float *)lw[7], *b2 = (const float *)lw[9];
+            SmallNorms nq, no, n1, n2;
+            if (l > 0) {   // x holds the previous layer's un-normalised output
+                nq.ln_gamma = g_prev, nq.ln_beta = b_prev, nq.ln_eps = d->ln_eps, nq.ln_stats_out = b.stats_b;
+                no.res_stats = b.stats_b, no.res_gamma = g_prev, no.res_beta = b_prev;
+            }
+            RUN(launch_linear(x, (int)T, H, lw[0], 3 * H, bqkv, MMRAG_ACT_NONE, nullptr, qkv, s, &nq));
+            RUN(mmrag_attention_f16(qkv, cu_seqlens, ctx, B, max_len, H, d->n_heads, causal, stream));
+            RUN(launch_linear(ctx, (int)T, H, lw[2], H, bo, MMRAG_ACT_NONE, x, y, s, &no));
+            n1.ln_gamma = g1, n1.ln_beta = b1n, n1.ln_eps = d->ln_eps, n1.ln_stats_out = b.stats_a;
+            RUN(launch_linear(y, (int)T, H, lw[6], I, bi, d->act, nullptr, hm, s, &n1));
+            n2.res_stats = b.stats_a, n2.res_gamma = g1, n2.res_beta = b1n;
+            RUN(launch_linear(hm, (int)T, I, lw[8], H, b2, MMRAG_ACT_NONE, y, x, s, &n2));
+            g_prev = (const float *)lw[10], b_prev = (const float *)lw[11];
+        }
+        MMRAG_CHECK_HIP(hipGetLastError());
+        RUN(mmrag_layernorm_f16(x, y, g_prev, b_prev, T, H, d->ln_eps, stream));
+        return mmrag_pool_normalize_f16(y, cu_seqlens, sel, out, B, H, d->pool, d->normalize, stream);
+    }
     for (int l = 0; l < L; ++l, lw += 12) {
         const float *bqkv = (const float *)lw[1], *bo = (const float *)lw[3];
         const float *g1 = (const float *)lw[4], *b1n = (const float *)lw[5];
@@ -1381,7 +1511,6 @@ static int encoder_body(const mmrag_encoder_desc *d, const void *const *lw, cons
             RUN(mmrag_linear_f16(hm, T, I, lw[8], H, b2, MMRAG_ACT_NONE, x, x, stream));
         }
     }
-    hipStream_t s = (hipStream_t)stream;
     if (d->arch == MMRAG_ARCH_BERT) {
         RUN(mmrag_pool_normalize_f16(x, cu_seqlens, sel, out, B, H, d->pool, d->normalize, stream));
     } else {

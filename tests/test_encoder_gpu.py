@@ -202,3 +202,40 @@ def test_full_forward_vs_oracle_and_transformers_golden(N, golden_dir, name, sha
     assert err <= 4e-3 and cos >= 0.9999, (float(err), float(cos))
     # and the fp16 device result stays close to the float32 transformers output
     assert (got * golden).sum(1).min() >= 0.999
+
+
+@pytest.mark.parametrize("hidden,heads,inter,lens", [(384, 12, 1536, [9]), (384, 12, 1536, [17, 5, 30]), (768, 12, 3072, [64]),
+                                                      (768, 12, 3072, [3, 40]), (1024, 16, 2048, [33])])
+def test_single_query_forward_without_layernorm_launches(N, hidden, heads, inter, lens):
+    """T <= 64 (the online /query shape) runs BERT with the LayerNorms folded into the neighbouring GEMMs
+    (csrc/encoder.hip "the single-query path without LayerNorm launches").  Same embeddings as the forward WITH the
+    LayerNorm launches (developer switch 512), which the oracle / transformers goldens pin; non-trivial gamma / beta;
+    one to three sequences, token blocks of 16 both full and ragged."""
+    import ctypes
+
+    from multimodal_rag_amd.encoder import DeviceEncoder, EncoderConfig, random_bert_weights
+
+    cfg = EncoderConfig("t", 4, hidden, heads, inter, vocab=2000, max_pos=128, max_seq_length=128, pool="mean")
+    w = random_bert_weights(cfg, seed=11, device="cuda:0", std=0.05)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for k in list(w):
+        if "LayerNorm.weight" in k:
+            w[k] = 1.0 + 0.3 * torch.randn(w[k].shape, device="cuda:0", generator=g)
+        elif "LayerNorm.bias" in k:
+            w[k] = 0.2 * torch.randn(w[k].shape, device="cuda:0", generator=g)
+    enc = DeviceEncoder(cfg, w, "cuda:0")
+    rng = np.random.default_rng(6)
+    seqs = [rng.integers(5, 2000, n).tolist() for n in lens]
+    L = N.lib()
+    L.mmrag_internal_set_debug.argtypes = [ctypes.c_uint]
+    try:
+        L.mmrag_internal_set_debug(512)          # DBG_ENCODER_LN_PASSES
+        ref = enc.encode_ids(seqs).cpu().numpy()
+        L.mmrag_internal_set_debug(0)
+        got = enc.encode_ids(seqs).cpu().numpy()
+        again = enc.encode_ids(seqs).cpu().numpy()
+    finally:
+        L.mmrag_internal_set_debug(0)
+    assert np.array_equal(got, again)
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-3
+    assert np.abs(got - ref).max() <= 1e-3, float(np.abs(got - ref).max())
