@@ -157,7 +157,8 @@ DBG_NO_PREPASS, DBG_8_WAVES, DBG_NO_QS, DBG_FORCE_QS = 1, 2, 4, 8
 
 def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, row_offset: int = 0,
                 alive_bits: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None, dbg: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+                workspace: Optional[torch.Tensor] = None, dbg: int = 0,
+                packed_out: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact cosine top-k of q [B, ld] against the first n rows of corpus [cap, ld].
 
     Returns (scores [B, k] float32 descending, rows [B, k] int64 global).  Both inputs must be
@@ -175,8 +176,13 @@ def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, r
     need = L.mmrag_cosine_topk_workspace_bytes(B, n, k)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
-    out_s = torch.empty((B, k), dtype=torch.float32, device=q.device)
-    out_r = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    if packed_out:   # ONE buffer [rows B*k int64 | scores B*k float32]: a caller that wants both on the host copies once
+        buf = torch.empty(B * k * 12, dtype=torch.uint8, device=q.device)
+        out_r = buf[: B * k * 8].view(torch.int64).view(B, k)
+        out_s = buf[B * k * 8:].view(torch.float32).view(B, k)
+    else:
+        out_s = torch.empty((B, k), dtype=torch.float32, device=q.device)
+        out_r = torch.empty((B, k), dtype=torch.int64, device=q.device)
     if dbg:
         cosine_topk_lists(q, corpus, n, d, k, workspace, alive_bits=alive_bits, dbg=dbg)
         return cosine_topk_select(B, n, k, row_offset, workspace, out_s, out_r)

@@ -137,6 +137,8 @@ class DeviceEncoder:
         # asyncio.to_thread workers, embedder.py:368, and ctypes drops the GIL).  Held while the kernels are
         # ENQUEUED; stream order then keeps the forwards apart on the device.
         self._launch_lock = threading.Lock()
+        self._graphs = {}                 # token count -> captured single-sequence forward (encode_one)
+        self._use_graphs = os.environ.get("MMRAG_ENCODER_GRAPHS", "1") not in ("0", "false", "no")
 
     # ---------------------------------------------------------------- constructors ---------
     @classmethod
@@ -186,6 +188,9 @@ class DeviceEncoder:
 
     def encode_ids(self, sequences: Sequence[Sequence[int]]) -> torch.Tensor:
         """Token-id sequences -> L2-normalised embeddings [B, dim] float32 on the device."""
+        if len(sequences) == 1 and 0 < len(sequences[0]) <= self.GRAPH_MAX_TOKENS and self._use_graphs:
+            L = min(self.cfg.max_seq_length, self.cfg.max_pos)
+            return self.encode_one(list(sequences[0])[:L])
         ids, pos, cu, max_len = self.pack(sequences)
         d = self.device
         ids_t = torch.from_numpy(ids).to(d, non_blocking=True)
@@ -200,6 +205,8 @@ class DeviceEncoder:
         lens = np.minimum(np.asarray(lens, dtype=np.int32), L)
         if lens.size == 0 or lens.min() <= 0:
             raise ValueError("empty token sequence")
+        if lens.size == 1 and lens[0] <= self.GRAPH_MAX_TOKENS and self._use_graphs:
+            return self.encode_one(ids2d[0, : int(lens[0])])
         W = ids2d.shape[1]
         keep = np.arange(W, dtype=np.int32)[None, :] < lens[:, None]
         ids = np.ascontiguousarray(ids2d[keep], dtype=np.int32)
@@ -210,6 +217,42 @@ class DeviceEncoder:
         return self.forward_packed(torch.from_numpy(ids).to(d, non_blocking=True),
                                    torch.from_numpy(np.ascontiguousarray(pos)).to(d, non_blocking=True),
                                    torch.from_numpy(cu).to(d, non_blocking=True), int(lens.max()))
+
+    # ---- one sequence of at most 64 tokens (the online /query shape): the forward is a chain of ~33 kernels of 3-5 us and
+    # the HOST's launch calls (4 us each) are what paces it.  The chain is captured once per token count into a HIP graph;
+    # a query then costs one small host-to-device copy, one graph launch and one copy of the result row.
+    GRAPH_MAX_TOKENS = 64
+
+    def _single_sequence_graph(self, T: int):
+        g = self._graphs.get(T)
+        if g is not None:
+            return g
+        d = self.device
+        ids = torch.full((T,), 5, dtype=torch.int32, device=d)
+        pos = torch.arange(T, dtype=torch.int32, device=d)
+        cu = torch.tensor([0, T], dtype=torch.int32, device=d)
+        need = _native.encoder_workspace_bytes(self.desc, T, 1)
+        ws = torch.empty(need, dtype=torch.uint8, device=d)      # the graph's own workspace: replays never share one
+        side = torch.cuda.Stream(d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):                              # warm-up outside the capture (lazy one-time setup)
+            _native.encoder_forward(self.desc, self._ptrs, ids, pos, cu, T, workspace=ws)
+        torch.cuda.current_stream(d).wait_stream(side)
+        torch.cuda.synchronize(d)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = _native.encoder_forward(self.desc, self._ptrs, ids, pos, cu, T, workspace=ws)
+        g = self._graphs[T] = (graph, ids, out, ws, pos, cu)
+        return g
+
+    def encode_one(self, token_ids) -> torch.Tensor:
+        """[1, dim] float32 on the device for ONE sequence of <= GRAPH_MAX_TOKENS token ids, through the captured graph."""
+        ids = np.ascontiguousarray(token_ids, dtype=np.int32)
+        with self._launch_lock:
+            graph, ids_dev, out = self._single_sequence_graph(int(ids.size))[:3]
+            ids_dev.copy_(torch.from_numpy(ids), non_blocking=True)
+            graph.replay()
+            return out.clone()        # the graph's output row is overwritten by the next replay
 
     def forward_packed(self, ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -180,6 +180,7 @@ class VectorIndex:
         self._meta_index = MetaIndex()
         self._row_of: Dict[str, int] = {}
         self._lock = threading.RLock()
+        self._search_ws: Optional[torch.Tensor] = None    # candidate-list workspace of the search kernels, reused
 
     @staticmethod
     def _n_words(rows: int) -> int:
@@ -265,6 +266,8 @@ class VectorIndex:
     def _pack_queries(self, q, check_norm: bool = True) -> torch.Tensor:
         """float32 [B, d] -> storage dtype [B, ld] with zero pad columns (device-side cast kernel)."""
         qf = self._to_device_f32(q, "query", check_norm)
+        if self.dtype == torch.float32 and self.ld == self.dim:
+            return qf          # already the stored form: no cast pass (one launch less on the single-query path)
         packed = torch.empty((qf.shape[0], self.ld), dtype=self.dtype, device=self.device)
         _native.append_rows(packed, 0, qf, self.dim)
         return packed
@@ -350,7 +353,14 @@ class VectorIndex:
         q = self._pack_queries(query_embeddings, check_norm)
         bits = self._where_bits(where)
         if n_results <= _native.MAX_K:
-            return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits)
+            need = _native.cosine_topk_workspace_bytes(q.shape[0], self._n, n_results)
+            if self._search_ws is None or self._search_ws.numel() < need:
+                self._search_ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+            # (one workspace per index: searches are enqueued under the lock on the caller's current stream, and every
+            # caller thread of the service uses the default stream, so consecutive scans are ordered on the device)
+            return _native.cosine_topk(q, self._matrix, self._n, self.dim, n_results, alive_bits=bits,
+                                       workspace=self._search_ws if torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device) else None,
+                                       packed_out=True)
         if q.shape[0] != 1:
             raise ValueError(f"n_results > {_native.MAX_K} is supported for single queries only")
         # deeper than the kernel's lists (get_similar_documents asks for n_results + 1): further passes with the rows
@@ -402,8 +412,15 @@ class VectorIndex:
 
     def _collect(self, scores, rows, include, ids_t, docs_t, metas_t, emb_src) -> Dict[str, Any]:
         # one device -> host copy each, then plain Python lists: per-element numpy scalars cost 10x a list item
-        rows_l = rows.cpu().tolist()
-        dist_l = (1.0 - scores).cpu().tolist() if "distances" in include else None   # float32 arithmetic, as before
+        if rows.is_cuda and rows._base is not None and scores._base is not None and rows._base.data_ptr() == scores._base.data_ptr():
+            host = rows._base.cpu()               # packed [rows | scores] (cosine_topk(packed_out=True)): ONE copy, one wait
+            nb = rows.numel()
+            rows_h = host[: nb * 8].view(torch.int64).view(rows.shape)
+            scores_h = host[nb * 8:].view(torch.float32).view(scores.shape)
+        else:
+            rows_h, scores_h = rows.cpu(), scores.cpu()
+        rows_l = rows_h.tolist()
+        dist_l = (1.0 - scores_h).tolist() if "distances" in include else None        # float32 arithmetic, as before
         want_m, want_d, want_e = "metadatas" in include, "documents" in include, "embeddings" in include
         out: Dict[str, Any] = {"ids": [], "distances": [] if dist_l is not None else None,
                                "metadatas": [] if want_m else None, "documents": [] if want_d else None,

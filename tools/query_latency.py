@@ -19,9 +19,12 @@ async def main():
                          metadatas=[{"type": "text"}] * 20000, ids=[f"doc_000000000000_t{i}" for i in range(lo, lo + 20000)])
     qs = [f"what is the meaning of topic number {i} in the retrieval pipeline" for i in range(60)]
     for q in qs[:10]: await m.query(q)
+    from multimodal_rag_amd import tracing
+    tracing.reset()
     t0 = time.perf_counter()
     for q in qs[10:]: await m.query(q)
     dt = (time.perf_counter() - t0) / 50
+    stages = {k: v["mean_ms"] for k, v in m.get_stage_timers().items()}
     eng = m._engine
     t0 = time.perf_counter()
     for q in qs[10:]: e = eng.encode([q])
@@ -32,6 +35,7 @@ async def main():
     t0 = time.perf_counter()
     for _ in range(50): r = m.collection.query([e[0].tolist()], n_results=5)
     ts = (time.perf_counter() - t0) / 50
+    print("stage means (ms) inside query():", stages)
     print(f"rows {n}: query() {dt*1e3:.2f} ms | encode {te*1e3:.2f} ms (tokenize {tt*1e3:.3f}) | collection.query {ts*1e3:.2f} ms")
     res = await m.batch_query(qs[:32]); t0 = time.perf_counter(); res = await m.batch_query(qs[:32]); tb = time.perf_counter() - t0
     print(f"batch_query(32): {tb*1e3:.2f} ms total")
