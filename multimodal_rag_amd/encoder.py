@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import json
+import logging
 import os
 import threading
 from dataclasses import dataclass
@@ -23,6 +24,8 @@ import numpy as np
 import torch
 
 from . import _native
+
+logger = logging.getLogger(__name__)
 
 
 @dataclass(frozen=True)
@@ -240,7 +243,8 @@ class DeviceEncoder:
         torch.cuda.current_stream(d).wait_stream(side)
         torch.cuda.synchronize(d)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: other threads of the service keep allocating and launching while this one captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = _native.encoder_forward(self.desc, self._ptrs, ids, pos, cu, T, workspace=ws)
         g = self._graphs[T] = (graph, ids, out, ws, pos, cu)
         return g
@@ -248,11 +252,24 @@ class DeviceEncoder:
     def encode_one(self, token_ids) -> torch.Tensor:
         """[1, dim] float32 on the device for ONE sequence of <= GRAPH_MAX_TOKENS token ids, through the captured graph."""
         ids = np.ascontiguousarray(token_ids, dtype=np.int32)
+        T = int(ids.size)
         with self._launch_lock:
-            graph, ids_dev, out = self._single_sequence_graph(int(ids.size))[:3]
-            ids_dev.copy_(torch.from_numpy(ids), non_blocking=True)
-            graph.replay()
-            return out.clone()        # the graph's output row is overwritten by the next replay
+            if self._graphs.get(T, 0) is None:      # capture failed once for this length: plain launches
+                g = None
+            else:
+                try:
+                    g = self._single_sequence_graph(T)
+                except RuntimeError as e:           # e.g. a capture invalidated by the runtime: never fatal
+                    logger.warning("HIP graph capture for %d tokens failed (%s): plain launches from now on", T, e)
+                    g = self._graphs[T] = None
+            if g is not None:
+                graph, ids_dev, out = g[:3]
+                ids_dev.copy_(torch.from_numpy(ids), non_blocking=True)
+                graph.replay()
+                return out.clone()    # the graph's output row is overwritten by the next replay
+        d = self.device
+        return self.forward_packed(torch.from_numpy(ids).to(d, non_blocking=True), torch.arange(T, dtype=torch.int32, device=d),
+                                   torch.tensor([0, T], dtype=torch.int32, device=d), T)
 
     def forward_packed(self, ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -433,3 +433,32 @@ def test_stage_timers_and_roctx_ranges_on_the_hip_path(gpu):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "ok 2" in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_single_queries_from_many_threads_through_the_graphs(gpu):
+    """one-sequence forwards replay a HIP graph captured per token count (DeviceEncoder.encode_one): captures happen while
+    other threads search and encode, answers equal the batched forward's"""
+    import threading
+
+    from multimodal_rag_amd.embedder import HipEngine
+
+    eng = HipEngine("sentence-transformers/all-MiniLM-L6-v2")
+    texts = [" ".join(f"w{(i * 7 + j) % 50}" for j in range(1 + (i * 5) % 40)) for i in range(48)]
+    ref = eng.encode(texts)                      # one batched forward (no graphs)
+    got = [None] * len(texts)
+    errs = []
+
+    def worker(lo):
+        try:
+            for i in range(lo, len(texts), 6):
+                got[i] = eng.encode([texts[i]])[0]
+        except Exception as e:                   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert len(eng.encoder._graphs) >= 5 and all(v is not None for v in eng.encoder._graphs.values())
+    assert np.abs(np.stack(got) - ref).max() <= 2e-3
