@@ -192,7 +192,7 @@ struct LinearParams {
 };
 
 template <int BF, int BT, int WF, int WT, int NSTAGE, bool PIPE = false>
-__global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(const LinearParams p) {
+__global__ __launch_bounds__(64 * WF *WT, (WF * WT) >= 4 ? (WF * WT) / 4 : 1) void linear_kernel(const LinearParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WF * WT;
     constexpr int RF = BF / (32 * WF);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WF *WT, (WF * WT) / 4) void linear_kernel(cons
     constexpr int STG_BYTES = BT * STG_ROW;
     constexpr int RING_BYTES = NSTAGE * STAGE;
     constexpr int LDS_BYTES = RING_BYTES > STG_BYTES ? RING_BYTES : STG_BYTES;
-    static_assert(PIECES % NW == 0 && W_PIECES % PW == 0, "piece split");
+    static_assert(PIECES % NW == 0 && (W_PIECES % PW == 0 || PW % W_PIECES == 0), "piece split");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
 
@@ -1312,6 +1312,13 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
             linear_kernel<256, 256, 4, 4, 2, true><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
     } else {
         const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+        if ((dbg & DBG_LINEAR_TILE64) || (!(dbg & DBG_LINEAR_TILE128) && tiles < cus / 2)) {
+            // a few hundred token rows (a dispatcher batch of queries): 128x128 tiles leave most CUs idle, 64x64 tiles of one
+            // wave each are four times as many workgroups
+            const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+            linear_kernel<64, 64, 1, 1, 2, true><<<(unsigned)t64, 64, 0, s>>>(p);
+            return MMRAG_OK;
+        }
         // 2 ring stages (64 KB) so two workgroups share a CU, pipelined fragment reads: +5 % on the ViT forward
         linear_kernel<128, 128, 2, 2, 2, true><<<(unsigned)tiles, 256, 0, s>>>(p);
     }

@@ -40,6 +40,7 @@ constexpr unsigned DBG_LINEAR_PLAIN = 1u, DBG_LINEAR_NO_SMALL = 2u, DBG_LINEAR_N
 constexpr unsigned DBG_LINEAR_DROP_STORES = 8u, DBG_LINEAR_SKIP_EPILOGUE = 16u;
 constexpr unsigned DBG_LINEAR_X_SAME = 128u;
 constexpr unsigned DBG_LINEAR_SMALL32 = 256u;
-constexpr unsigned DBG_ENCODER_LN_PASSES = 512u;   // BERT single-query forward with LayerNorm launches (A/B, tests)   // M <= 64: the 32-feature workgroups for every K (A/B)   // timing only: every tile reads the first token tile
+constexpr unsigned DBG_ENCODER_LN_PASSES = 512u;
+constexpr unsigned DBG_LINEAR_TILE64 = 1024u, DBG_LINEAR_TILE128 = 2048u;   // mid-size M: force 64x64 / 128x128 tiles (A/B)   // BERT single-query forward with LayerNorm launches (A/B, tests)   // M <= 64: the 32-feature workgroups for every K (A/B)   // timing only: every tile reads the first token tile
 
 }  // namespace mmrag
