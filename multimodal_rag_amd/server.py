@@ -72,164 +72,187 @@ def parse_multipart_file(content_type: str, body: bytes, field: str = "file"):
     return None
 
 
-class _Upload:
-    def __init__(self, filename, content_type, data):
-        self.filename, self.content_type, self._data = filename, content_type, data
+class Pipeline:
+    """The stages behind the routes.  The stages this package does not own (parser, summariser, text / multimodal
+    generators) are whatever the caller passes to `create_app`, else the stand-ins of ingest.py."""
 
-    async def read(self) -> bytes:
-        return self._data
+    CONTEXT_KINDS = ("text_chunks", "table_chunks", "image_chunks")
+
+    def __init__(self, parts: dict):
+        self.parts = parts
+
+    def __getattr__(self, name):          # pipeline.embedder, pipeline.retriever, ...
+        try:
+            return self.__dict__["parts"][name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    async def start(self):
+        p = self.parts
+        p["parser"] = p["parser"] or TextDocumentParser()
+        p["llm"] = p["llm"] or ExtractiveAnswerer()
+        p["mllm"] = p["mllm"] or p["llm"]
+        await p["llm"].initialize()
+        p["summarizer"] = p["summarizer"] or PassthroughSummarizer(p["mllm"])
+        p["embedder"] = p["embedder"] or EmbeddingManager(batch_size=32, enable_cache=True)
+        p["retriever"] = p["retriever"] or MultiVectorRetriever(enable_compression=True, enable_cache=True)
+        for name in ("embedder", "retriever"):
+            await p[name].initialize()
+
+    async def stop(self):
+        for name in ("llm", "embedder", "retriever"):
+            try:
+                await self.parts[name].cleanup()
+            except Exception as e:  # pragma: no cover
+                logger.error("Cleanup error: %s", e)
+
+    async def ingest(self, filename: str, content_type: Optional[str], data: bytes) -> dict:
+        """parse -> summarise -> embed + store vectors -> store raw items (api.py:262-300); returns the UploadResponse
+        fields except the timing ones"""
+        doc_id = "doc_" + uuid.uuid4().hex[:12]
+        tree = await self.parser.parse_document(data, filename, content_type, doc_id=doc_id)
+        items = await self.summarizer.summarize_parsed_document(tree, max_length=300, show_progress=True)
+        if not items:
+            raise HTTPException(status_code=status.HTTP_400_BAD_REQUEST, detail="No content extracted")
+        stored = await self.embedder.embed_and_store(items, doc_id)
+        await self.retriever.store_raw_documents(doc_id, items, filename)
+        return {"doc_id": doc_id, "filename": filename, "doc_type": tree.get("doc_type", "unknown"),
+                "chunks_processed": stored}
+
+    async def answer(self, question: str, top_k: int, multimodal: bool) -> Optional[dict]:
+        """vector search -> raw items -> generator (api.py:338-400); None when nothing was retrieved"""
+        hits = await self.embedder.query(question, n_results=top_k)
+        if not hits["ids"]:
+            return None
+        raw = await self.retriever.retrieve_raw_documents(hits["ids"])
+        passages, tables, images = (raw[k] for k in self.CONTEXT_KINDS)
+        body = "\n\n".join(passages) if passages else ""
+        if multimodal and (images or tables):
+            text = await self.mllm.generate_multimodal(text=body, tables=tables, images=images, max_tokens=1000,
+                                                       temperature=0.7)
+        else:
+            if tables:
+                body += "\n\nBảng:\n" + "\n\n".join(tables)
+            text = await self.llm.generate_text(f"Context:\n{body}\n\nCâu hỏi: {question}\n\nTrả lời:",
+                                                max_tokens=1000, temperature=0.7)
+        ranked = [{"rank": at, "doc_id": found, "relevance_score": round(float(1.0 - min(dist, 1.0)), 3),   # api.py:390
+                   "type": meta.get("type", "unknown")}
+                  for at, (found, dist, meta) in enumerate(zip(hits["ids"], hits["distances"], hits["metadatas"]), 1)]
+        return {"answer": text, "sources": ranked}
+
+    async def health(self) -> dict:
+        parts = {"llm_adapter": await self.llm.health_check(),
+                 "embedder": {"status": "healthy",
+                              "documents": (await self.embedder.get_collection_stats()).get("count", 0)},
+                 "retriever": await self.retriever.health_check()}
+        fine = all(v.get("status") == "healthy" or v.get("healthy") is True for v in parts.values())
+        return {"status": "healthy" if fine else "degraded", "components": parts,
+                "timestamp": datetime.utcnow().isoformat(), "auth": "disabled"}
+
+    async def report(self) -> dict:
+        emb, ret, summ = [await self.parts[n].get_stats() for n in ("embedder", "retriever", "summarizer")]
+        listing = await self.retriever.list_all_documents()
+        per_kind = {kind: sum(doc.get("chunks", {}).get(kind, 0) for doc in listing) for kind in ("text", "table", "image")}
+        return {"documents": {"total": len(listing), "total_chunks": emb.get("count", 0), "by_type": per_kind},
+                "embedder": {"cache_hit_rate": emb.get("cache", {}).get("hit_rate", 0)},
+                "retriever": {"compression_enabled": ret.get("features", {}).get("compression", False),
+                              "compression_savings": ret.get("compression", {}).get("savings_percent", 0)},
+                "summarizer": {"total_summaries": summ.get("total_summaries", 0),
+                               "cache_hit_rate": summ.get("cache", {}).get("hit_rate", 0)},
+                "auth": "disabled"}
+
+
+def _as_http_500(fn):
+    """route wrapper: anything but an HTTPException becomes a 500 with the message as detail (the reference's blanket
+    `except Exception` around every route body)"""
+    import functools
+
+    @functools.wraps(fn)
+    async def wrapped(*a, **kw):
+        try:
+            return await fn(*a, **kw)
+        except HTTPException:
+            raise
+        except Exception as e:
+            logger.error("%s failed: %s", fn.__name__, e, exc_info=True)
+            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+
+    return wrapped
 
 
 def create_app(embedder: Optional[Any] = None, retriever: Optional[Any] = None, parser: Optional[Any] = None,
                summarizer: Optional[Any] = None, llm_adapter: Optional[Any] = None,
                mllm_adapter: Optional[Any] = None) -> FastAPI:
-    c = {"embedder": embedder, "retriever": retriever, "parser": parser, "summarizer": summarizer,
-         "llm": llm_adapter, "mllm": mllm_adapter}
+    pipe = Pipeline({"embedder": embedder, "retriever": retriever, "parser": parser, "summarizer": summarizer,
+                     "llm": llm_adapter, "mllm": mllm_adapter})
 
     @asynccontextmanager
     async def lifespan(app: FastAPI):  # api.py:65-128
-        c["parser"] = c["parser"] or TextDocumentParser()
-        c["llm"] = c["llm"] or ExtractiveAnswerer()
-        c["mllm"] = c["mllm"] or c["llm"]
-        await c["llm"].initialize()
-        c["summarizer"] = c["summarizer"] or PassthroughSummarizer(c["mllm"])
-        c["embedder"] = c["embedder"] or EmbeddingManager(batch_size=32, enable_cache=True)
-        await c["embedder"].initialize()
-        c["retriever"] = c["retriever"] or MultiVectorRetriever(enable_compression=True, enable_cache=True)
-        await c["retriever"].initialize()
+        await pipe.start()
         yield
-        for name in ("llm", "embedder", "retriever"):
-            try:
-                await c[name].cleanup()
-            except Exception as e:  # pragma: no cover
-                logger.error("Cleanup error: %s", e)
+        await pipe.stop()
 
     app = FastAPI(title="Multi-modal RAG System (MI355X hot path)", version="2.0.0", lifespan=lifespan)
-    app.state.components = c
+    app.state.components = pipe.parts
 
     @app.get("/health")
-    async def health_check():  # api.py:202-241
+    async def health_check():  # api.py:202-241: never raises
         try:
-            comp = {"llm_adapter": await c["llm"].health_check()}
-            stats = await c["embedder"].get_collection_stats()
-            comp["embedder"] = {"status": "healthy", "documents": stats.get("count", 0)}
-            comp["retriever"] = await c["retriever"].health_check()
-            ok = all(x.get("status") == "healthy" or x.get("healthy") is True for x in comp.values())
-            return {"status": "healthy" if ok else "degraded", "components": comp,
-                    "timestamp": datetime.utcnow().isoformat(), "auth": "disabled"}
+            return await pipe.health()
         except Exception as e:
             return {"status": "unhealthy", "error": str(e)}
 
     @app.post("/upload", response_model=UploadResponse)
+    @_as_http_500
     async def upload_document(request: Request):  # api.py:244-322
-        start_time = time.time()
-        parsed_form = parse_multipart_file(request.headers.get("content-type", ""), await request.body())
-        if parsed_form is None:  # FastAPI's own answer to a missing File(...) field
+        t0 = time.time()
+        form = parse_multipart_file(request.headers.get("content-type", ""), await request.body())
+        if form is None:  # FastAPI's own answer to a missing File(...) field
             raise HTTPException(status_code=422, detail=[{"loc": ["body", "file"], "msg": "Field required",
                                                           "type": "missing"}])
-        file = _Upload(*parsed_form)
-        if not file.filename:
+        filename, content_type, data = form
+        if not filename:
             raise HTTPException(status_code=status.HTTP_400_BAD_REQUEST, detail="Filename is required")
-        content = await file.read()
-        if len(content) / (1024 * 1024) > settings.MAX_UPLOAD_SIZE:
-            raise HTTPException(status_code=413,
-                                detail=f"File too large. Max: {settings.MAX_UPLOAD_SIZE}MB")
-        try:
-            doc_id = f"doc_{uuid.uuid4().hex[:12]}"
-            parsed = await c["parser"].parse_document(content, file.filename, file.content_type, doc_id=doc_id)
-            doc_type = parsed.get("doc_type", "unknown")
-            all_summaries = await c["summarizer"].summarize_parsed_document(parsed, max_length=300, show_progress=True)
-            if not all_summaries:
-                raise HTTPException(status_code=status.HTTP_400_BAD_REQUEST, detail="No content extracted")
-            counts = await c["embedder"].embed_and_store(all_summaries, doc_id)
-            await c["retriever"].store_raw_documents(doc_id, all_summaries, file.filename)
-            total_time = time.time() - start_time
-            return {"doc_id": doc_id, "filename": file.filename, "doc_type": doc_type, "chunks_processed": counts,
-                    "message": f"Processed in {total_time:.2f}s", "processing_time": total_time}
-        except HTTPException:
-            raise
-        except Exception as e:
-            logger.error("Upload failed: %s", e, exc_info=True)
-            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+        if len(data) > settings.MAX_UPLOAD_SIZE * 1024 * 1024:
+            raise HTTPException(status_code=413, detail=f"File too large. Max: {settings.MAX_UPLOAD_SIZE}MB")
+        out = await pipe.ingest(filename, content_type, data)
+        took = time.time() - t0
+        return {**out, "message": f"Processed in {took:.2f}s", "processing_time": took}
 
     @app.post("/query", response_model=QueryResponse)
+    @_as_http_500
     async def query_documents(request: QueryRequest):  # api.py:325-413
-        start_time = time.time()
-        try:
-            search_results = await c["embedder"].query(request.query, n_results=request.top_k)
-            if not search_results["ids"]:
-                return {"answer": NO_DOCS_ANSWER, "sources": [], "processing_time": time.time() - start_time}
-            raw_docs = await c["retriever"].retrieve_raw_documents(search_results["ids"])
-            text_context = "\n\n".join(raw_docs["text_chunks"]) if raw_docs["text_chunks"] else ""
-            table_context = raw_docs["table_chunks"]
-            image_context = raw_docs["image_chunks"]
-            if request.use_multimodal and (image_context or table_context):
-                answer = await c["mllm"].generate_multimodal(text=text_context, tables=table_context,
-                                                             images=image_context, max_tokens=1000, temperature=0.7)
-            else:
-                full_context = text_context
-                if table_context:
-                    full_context += "\n\nBảng:\n" + "\n\n".join(table_context)
-                prompt = f"Context:\n{full_context}\n\nCâu hỏi: {request.query}\n\nTrả lời:"
-                answer = await c["llm"].generate_text(prompt, max_tokens=1000, temperature=0.7)
-            sources = []
-            for i, (doc_id, distance, metadata) in enumerate(zip(search_results["ids"], search_results["distances"],
-                                                                 search_results["metadatas"])):
-                relevance_score = float(1.0 - min(distance, 1.0))  # api.py:390
-                sources.append({"rank": i + 1, "doc_id": doc_id, "relevance_score": round(relevance_score, 3),
-                                "type": metadata.get("type", "unknown")})
-            return {"answer": answer, "sources": sources, "processing_time": time.time() - start_time}
-        except Exception as e:
-            logger.error("Query failed: %s", e, exc_info=True)
-            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+        t0 = time.time()
+        out = await pipe.answer(request.query, request.top_k, request.use_multimodal)
+        if out is None:
+            out = {"answer": NO_DOCS_ANSWER, "sources": []}
+        return {**out, "processing_time": time.time() - t0}
 
     @app.get("/documents")
+    @_as_http_500
     async def list_documents():  # api.py:416-429
-        try:
-            documents = await c["retriever"].list_all_documents()
-            return {"total": len(documents), "documents": documents}
-        except Exception as e:
-            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+        listing = await pipe.retriever.list_all_documents()
+        return {"total": len(listing), "documents": listing}
 
     @app.delete("/documents/{doc_id}")
+    @_as_http_500
     async def delete_document(doc_id: str):  # api.py:432-445
-        try:
-            await c["embedder"].delete_document(doc_id)
-            await c["retriever"].delete_document(doc_id)
-            return {"message": f"Document {doc_id} deleted"}
-        except Exception as e:
-            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+        for store in (pipe.embedder, pipe.retriever):
+            await store.delete_document(doc_id)
+        return {"message": f"Document {doc_id} deleted"}
 
     @app.delete("/documents")
+    @_as_http_500
     async def delete_all_documents():  # api.py:448-465
-        try:
-            count = len(await c["retriever"].list_all_documents())
-            await c["embedder"].delete_all_documents()
-            await c["retriever"].delete_all_documents()
-            return {"message": f"Deleted {count} documents", "count": count}
-        except Exception as e:
-            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+        n = len(await pipe.retriever.list_all_documents())
+        for store in (pipe.embedder, pipe.retriever):
+            await store.delete_all_documents()
+        return {"message": f"Deleted {n} documents", "count": n}
 
     @app.get("/stats")
+    @_as_http_500
     async def get_stats():  # api.py:468-508
-        try:
-            e = await c["embedder"].get_stats()
-            r = await c["retriever"].get_stats()
-            s = await c["summarizer"].get_stats()
-            documents = await c["retriever"].list_all_documents()
-            by = {t: sum(d.get("chunks", {}).get(t, 0) for d in documents) for t in ("text", "table", "image")}
-            return {
-                "documents": {"total": len(documents), "total_chunks": e.get("count", 0),
-                              "by_type": {"text": by["text"], "table": by["table"], "image": by["image"]}},
-                "embedder": {"cache_hit_rate": e.get("cache", {}).get("hit_rate", 0)},
-                "retriever": {"compression_enabled": r.get("features", {}).get("compression", False),
-                              "compression_savings": r.get("compression", {}).get("savings_percent", 0)},
-                "summarizer": {"total_summaries": s.get("total_summaries", 0),
-                               "cache_hit_rate": s.get("cache", {}).get("hit_rate", 0)},
-                "auth": "disabled",
-            }
-        except Exception as e:
-            raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR, detail=str(e))
+        return await pipe.report()
 
     return app
 
