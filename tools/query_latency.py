@@ -11,6 +11,13 @@ async def main():
         _native.lib().mmrag_internal_set_debug(ctypes.c_uint(int(os.environ["MMRAG_DEBUG"])))
     m = EmbeddingManager(batch_size=32, enable_cache=False)
     await m.initialize()
+    if os.environ.get("TOKENIZER", "native") == "native":
+        # a deployment has vocab.txt and therefore the native WordPiece tokenizer; without a checkpoint the engine falls back to
+        # the pure-Python hash tokenizer (TOKENIZER=hash keeps it).  Same synthetic vocabulary as bench.py's served leg.
+        from bench_embed import synthetic_vocab
+        from multimodal_rag_amd.tokenizer import NativeWordPieceTokenizer
+        vocab, words = synthetic_vocab(m._engine.encoder.cfg.vocab)
+        m._engine.tokenizer = NativeWordPieceTokenizer(vocab)
     n = int(os.environ.get("ROWS", "100000"))
     g = np.random.default_rng(0)
     v = g.standard_normal((n, 384)).astype(np.float32); v /= np.linalg.norm(v, axis=1, keepdims=True)
@@ -18,6 +25,8 @@ async def main():
         m.collection.add(v[lo:lo + 20000], documents=[f"d{i}" for i in range(lo, lo + 20000)],
                          metadatas=[{"type": "text"}] * 20000, ids=[f"doc_000000000000_t{i}" for i in range(lo, lo + 20000)])
     qs = [f"what is the meaning of topic number {i} in the retrieval pipeline" for i in range(60)]
+    if os.environ.get("TOKENIZER", "native") == "native":
+        qs = [" ".join(words[(i * 13 + j * 101) % len(words)] for j in range(11)) for i in range(60)]
     for q in qs[:10]: await m.query(q)
     from multimodal_rag_amd import tracing
     tracing.reset()
