@@ -712,8 +712,10 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
 // qkv is [T, 3H] fp16 (Q | K | V column blocks).  One workgroup = (128-query tile, head, seq),
 // 4 waves x 32 queries; keys are consumed in tiles of 64.
 // ---------------------------------------------------------------------------------------------
-template <int DH, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__restrict__ qkv,
+// RESIDENT (sequences of at most 256 keys): all of K and V^T of the (sequence, head) is staged once, ONE barrier, and the
+// waves then walk the key tiles on their own -- no per-tile staging, no per-tile barrier.
+template <int DH, int OCC = 1, bool RESIDENT = false, int NWAVES = 4>   // NWAVES x 32 queries per workgroup
+__global__ __launch_bounds__(64 * NWAVES, OCC) void attention_kernel(const _Float16 *__restrict__ qkv,
                                                             const int *__restrict__ cu_seqlens,
                                                             _Float16 *__restrict__ ctx, int H, float scale,
                                                             int causal) {
@@ -727,7 +729,8 @@ __global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__r
     constexpr int V_BYTES = DH * VROW;
     constexpr int NQK = DH / 16;           // MFMA k-steps for Q.K^T
     constexpr int NDB = DH / 32;           // 32-row blocks of O^T
-    __shared__ __attribute__((aligned(16))) char smem[2 * (K_BYTES + V_BYTES)];
+    constexpr int NBUF = RESIDENT ? 4 : 2;  // key tiles held in LDS
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * (K_BYTES + V_BYTES)];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -736,7 +739,8 @@ __global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__r
     const int head = blockIdx.y;
     const int seq0 = cu_seqlens[blockIdx.z];
     const int len = cu_seqlens[blockIdx.z + 1] - seq0;
-    const int q_tile0 = blockIdx.x * 128;
+    constexpr int QT = 32 * NWAVES, NT = 64 * NWAVES;
+    const int q_tile0 = blockIdx.x * QT;
     if (q_tile0 >= len) return;
     const int ld = 3 * H;
     const _Float16 *Qp = qkv + (size_t)seq0 * ld + head * DH;
@@ -755,36 +759,36 @@ __global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__r
             for (int i = 0; i < 8; ++i) qf[ks][i] = (_Float16)0.f;
     }
 
-    const int kv_end = causal ? ((q_tile0 + 128 < len) ? q_tile0 + 128 : len) : len;
+    const int kv_end = causal ? ((q_tile0 + QT < len) ? q_tile0 + QT : len) : len;
     const int n_tiles = (kv_end + KT - 1) / KT;
 
     // staging assignment.  K: 16-byte chunk (key, c) per thread-iteration, coalesced.
     // V: lane = key, so the transposed 2-byte LDS writes of a wave are contiguous.
-    constexpr int K_ITERS = (KT * CH) / 256 > 0 ? (KT * CH) / 256 : 1;
-    constexpr int V_ITERS = CH / 4 > 0 ? CH / 4 : 1;  // d-chunks per wave
-    uint4 kreg[K_ITERS], vreg[V_ITERS];
-    auto load_tile = [&](int kt) {
+    constexpr int K_ITERS = (KT * CH) / NT > 0 ? (KT * CH) / NT : 1;
+    constexpr int V_ITERS = CH / NWAVES > 0 ? CH / NWAVES : 1;  // d-chunks per wave
+    uint4 kreg0[K_ITERS], vreg0[V_ITERS];
+    auto load_tile_into = [&](int kt, uint4(&kreg)[K_ITERS], uint4(&vreg)[V_ITERS]) {
         const int k0 = kt * KT;
 #pragma unroll
         for (int i = 0; i < K_ITERS; ++i) {
-            const int idx = threadIdx.x + i * 256;
+            const int idx = threadIdx.x + i * NT;
             const int key = idx / CH, c = idx % CH;
             kreg[i] = make_uint4(0, 0, 0, 0);
             if (idx < KT * CH && k0 + key < len) kreg[i] = *(const uint4 *)(Kp + (size_t)(k0 + key) * ld + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < V_ITERS; ++i) {
-            const int c = wave + i * 4;
+            const int c = wave + i * NWAVES;
             vreg[i] = make_uint4(0, 0, 0, 0);
             if (c < CH && k0 + lane < len) vreg[i] = *(const uint4 *)(Vp + (size_t)(k0 + lane) * ld + c * 8);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile_from = [&](int buf, const uint4(&kreg)[K_ITERS], const uint4(&vreg)[V_ITERS]) {
         char *kb = smem + buf * (K_BYTES + V_BYTES);
         char *vb = kb + K_BYTES;
 #pragma unroll
         for (int i = 0; i < K_ITERS; ++i) {
-            const int idx = threadIdx.x + i * 256;
+            const int idx = threadIdx.x + i * NT;
             const int key = idx / CH, c = idx % CH;
             if (idx < KT * CH) {
                 const int cs = DH == 64 ? (c ^ ((key >> 1) & 7)) : (c ^ ((key >> 2) & 3));
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__r
         }
 #pragma unroll
         for (int i = 0; i < V_ITERS; ++i) {
-            const int c = wave + i * 4;
+            const int c = wave + i * NWAVES;
             if (c < CH) {
                 const unsigned w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
 #pragma unroll
@@ -812,12 +816,28 @@ __global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__r
         for (int j = 0; j < 16; ++j) o[d][j] = 0.f;
     float m_run = NEG_INF_F, l_run = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    auto load_tile = [&](int kt) { load_tile_into(kt, kreg0, vreg0); };
+    auto store_tile = [&](int buf) { store_tile_from(buf, kreg0, vreg0); };
+    if constexpr (RESIDENT) {
+        // every tile's loads in flight together (one memory latency), then the LDS writes, then the only barrier
+        uint4 kr[3][K_ITERS], vr[3][V_ITERS];
+        load_tile(0);
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (t < n_tiles) load_tile_into(t, kr[t - 1], vr[t - 1]);
+        store_tile(0);
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (t < n_tiles) store_tile_from(t, kr[t - 1], vr[t - 1]);
+    } else {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < n_tiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < n_tiles) load_tile(kt + 1);
+        const int buf = RESIDENT ? kt : (kt & 1);
+        if constexpr (!RESIDENT)
+            if (kt + 1 < n_tiles) load_tile(kt + 1);
         const char *kb = smem + buf * (K_BYTES + V_BYTES);
         const char *vb = kb + K_BYTES;
 
@@ -899,8 +919,10 @@ __global__ __launch_bounds__(256, OCC) void attention_kernel(const _Float16 *__r
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b][st], o[d], 0, 0, 0);
                 }
         }
-        if (kt + 1 < n_tiles) store_tile(buf ^ 1);
-        __syncthreads();
+        if constexpr (!RESIDENT) {
+            if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -1380,10 +1402,20 @@ int mmrag_attention_f16(const void *qkv, const int32_t *cu_seqlens, void *ctx, i
     const float scale = 1.0f / sqrtf((float)dh);
     // 3 waves per SIMD (<= 168 registers): -25 % vs the unconstrained 194-register build, which only fits 2
     // (A/B in one process, tools/attn_bench.py; 4 per SIMD spills and is slower)
-    if (dh == 64)
+    if (dh == 64 && max_len <= 256 && max_len > 128 && !(debug_flags() & DBG_ATTENTION_STREAMED)) {
+        // at most four key tiles: K and V^T of the whole sequence stay in LDS (66 KB: two workgroups per CU), shared by
+        // all 256 queries of the (sequence, head): 8 waves per workgroup, 4 per SIMD
+        const dim3 grid8((unsigned)((max_len + 255) / 256), (unsigned)n_heads, (unsigned)B);
+        attention_kernel<64, 2, true, 8><<<grid8, 512, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
+                                                                                 (_Float16 *)ctx, H, scale, causal);
+    } else if (dh == 64)
         attention_kernel<64, 3><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
                                                                        (_Float16 *)ctx, H, scale, causal);
-    else
+    else if (max_len <= 256 && max_len > 128 && !(debug_flags() & DBG_ATTENTION_STREAMED)) {
+        const dim3 grid8((unsigned)((max_len + 255) / 256), (unsigned)n_heads, (unsigned)B);
+        attention_kernel<32, 2, true, 8><<<grid8, 512, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
+                                                                                 (_Float16 *)ctx, H, scale, causal);
+    } else
         attention_kernel<32, 3><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
                                                                        (_Float16 *)ctx, H, scale, causal);
     MMRAG_CHECK_HIP(hipGetLastError());

@@ -41,6 +41,7 @@ constexpr unsigned DBG_LINEAR_DROP_STORES = 8u, DBG_LINEAR_SKIP_EPILOGUE = 16u;
 constexpr unsigned DBG_LINEAR_X_SAME = 128u;
 constexpr unsigned DBG_LINEAR_SMALL32 = 256u;
 constexpr unsigned DBG_ENCODER_LN_PASSES = 512u;
+constexpr unsigned DBG_ATTENTION_STREAMED = 4096u;   // attention: the double-buffered key-tile loop also for short sequences (A/B)
 constexpr unsigned DBG_LINEAR_TILE64 = 1024u, DBG_LINEAR_TILE128 = 2048u;   // mid-size M: force 64x64 / 128x128 tiles (A/B)   // BERT single-query forward with LayerNorm launches (A/B, tests)   // M <= 64: the 32-feature workgroups for every K (A/B)   // timing only: every tile reads the first token tile
 
 }  // namespace mmrag

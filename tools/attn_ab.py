@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodal_rag_amd import _native as N
-B, S, H, nh = 256, int(os.environ.get("S", "256")), 768, 12
+B, S, H, nh = 256, int(os.environ.get("S", "256")), int(os.environ.get("H", "768")), 12
 qkv = (torch.randn((B * S, 3 * H), device="cuda") * 0.5).half()
 cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device="cuda")
 ctx = torch.empty((B * S, H), dtype=torch.float16, device="cuda")
