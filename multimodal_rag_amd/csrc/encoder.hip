@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
 // ---------------------------------------------------------------------------------------------
 // RESIDENT (sequences of at most 256 keys): all of K and V^T of the (sequence, head) is staged once, ONE barrier, and the
 // waves then walk the key tiles on their own -- no per-tile staging, no per-tile barrier.
-template <int DH, int OCC = 1, bool RESIDENT = false, int NWAVES = 4>   // NWAVES x 32 queries per workgroup
+template <int DH, int OCC = 1, bool RESIDENT = false, int NWAVES = 4, int MAXT = 4>   // NWAVES x 32 queries per workgroup; RESIDENT: <= MAXT key tiles
 __global__ __launch_bounds__(64 * NWAVES, OCC) void attention_kernel(const _Float16 *__restrict__ qkv,
                                                             const int *__restrict__ cu_seqlens,
                                                             _Float16 *__restrict__ ctx, int H, float scale,
@@ -729,7 +729,8 @@ __global__ __launch_bounds__(64 * NWAVES, OCC) void attention_kernel(const _Floa
     constexpr int V_BYTES = DH * VROW;
     constexpr int NQK = DH / 16;           // MFMA k-steps for Q.K^T
     constexpr int NDB = DH / 32;           // 32-row blocks of O^T
-    constexpr int NBUF = RESIDENT ? 4 : 2;  // key tiles held in LDS
+    constexpr int NBUF = RESIDENT ? MAXT : 2;  // key tiles held in LDS
+    static_assert(NBUF * (K_BYTES + V_BYTES) <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[NBUF * (K_BYTES + V_BYTES)];
 
     const int lane = threadIdx.x & 63;
@@ -820,14 +821,14 @@ __global__ __launch_bounds__(64 * NWAVES, OCC) void attention_kernel(const _Floa
     auto store_tile = [&](int buf) { store_tile_from(buf, kreg0, vreg0); };
     if constexpr (RESIDENT) {
         // every tile's loads in flight together (one memory latency), then the LDS writes, then the only barrier
-        uint4 kr[3][K_ITERS], vr[3][V_ITERS];
+        uint4 kr[MAXT - 1][K_ITERS], vr[MAXT - 1][V_ITERS];
         load_tile(0);
 #pragma unroll
-        for (int t = 1; t < 4; ++t)
+        for (int t = 1; t < MAXT; ++t)
             if (t < n_tiles) load_tile_into(t, kr[t - 1], vr[t - 1]);
         store_tile(0);
 #pragma unroll
-        for (int t = 1; t < 4; ++t)
+        for (int t = 1; t < MAXT; ++t)
             if (t < n_tiles) store_tile_from(t, kr[t - 1], vr[t - 1]);
     } else {
         load_tile(0);
@@ -1408,6 +1409,11 @@ int mmrag_attention_f16(const void *qkv, const int32_t *cu_seqlens, void *ctx, i
         const dim3 grid8((unsigned)((max_len + 255) / 256), (unsigned)n_heads, (unsigned)B);
         attention_kernel<64, 2, true, 8><<<grid8, 512, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
                                                                                  (_Float16 *)ctx, H, scale, causal);
+    } else if (dh == 64 && max_len > 256 && max_len <= 512 && !(debug_flags() & DBG_ATTENTION_STREAMED)) {
+        // up to eight key tiles resident (132 KB): one workgroup of 16 waves (512 queries) per CU
+        const dim3 grid16((unsigned)((max_len + 511) / 512), (unsigned)n_heads, (unsigned)B);
+        attention_kernel<64, 1, true, 16, 8><<<grid16, 1024, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
+                                                                                       (_Float16 *)ctx, H, scale, causal);
     } else if (dh == 64)
         attention_kernel<64, 3><<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)qkv, cu_seqlens,
                                                                        (_Float16 *)ctx, H, scale, causal);

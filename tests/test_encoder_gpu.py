@@ -143,6 +143,10 @@ def test_embed_ln(N):
     (768, 12, [300, 5, 512, 77], False),
     (128, 4, [33, 64], False),
     (512, 8, [77, 20, 77], True),
+    (768, 12, [200, 140, 256], True),      # K / V resident in LDS (129-256 keys), causal
+    (384, 12, [130, 255], True),
+    (768, 12, [300, 400, 31], True),       # resident, up to 512 keys
+    (768, 12, [129, 256, 200, 3], False),
 ])
 def test_attention(N, H, heads, lens, causal):
     g = np.random.default_rng(H + len(lens))
