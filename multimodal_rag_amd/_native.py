@@ -153,6 +153,9 @@ def padded_dim(d: int, dtype: torch.dtype) -> int:
 
 # kernel-shape switches of the debug entry point (tests / A-B tools; the product always passes 0)
 DBG_NO_PREPASS, DBG_8_WAVES, DBG_NO_QS, DBG_FORCE_QS = 1, 2, 4, 8
+# query-stationary shapes: three-launch plan instead of the single-launch walk; the walk's MFMA shape forced; static tile
+# assignment only; no in-kernel threshold seeding (A/B tools and the tests that pin every code path)
+DBG_OLD_QS, DBG_MFMA32, DBG_MFMA16, DBG_NO_DYN, DBG_NO_SEED = 0x10000, 0x20000, 0x40000, 0x80000, 0x100000
 
 
 def cosine_topk(q: torch.Tensor, corpus: torch.Tensor, n: int, d: int, k: int, row_offset: int = 0,

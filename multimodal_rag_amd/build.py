@@ -20,7 +20,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmmrag.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
-SOURCES = ["common.hip", "search.hip", "search_qs.hip", "encoder.hip", "image.hip", "microbench.hip", "host_merge.cpp", "tokenizer.cpp"]
+SOURCES = ["common.hip", "search.hip", "search_qs.hip", "search_qsw.hip", "encoder.hip", "image.hip", "microbench.hip", "host_merge.cpp", "tokenizer.cpp"]
 ARCH = "gfx950"
 
 
@@ -55,6 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m)
         if stale:
             cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-I", INCLUDE, "-c", src, "-o", obj]
+            cmd[1:1] = os.environ.get("MMRAG_HIPCC_FLAGS", "").split()   # developer builds (e.g. -DMMRAG_QSW_DEV)
             if s.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

@@ -515,6 +515,10 @@ struct Plan {
 
 // debug switches of mmrag_internal_cosine_topk_lists_ex (tests and A/B tools only; never set by the product)
 constexpr unsigned DBG_NO_PREPASS = 1u, DBG_8_WAVES = 2u, DBG_NO_QS = 4u, DBG_FORCE_QS = 8u;
+// query-stationary shapes: the three-launch plan of search_qs.hip instead of the single-launch walk (A/B, tests); the
+// walk's MFMA shape forced to 32x32x16 / 16x16x32; no dynamic tile hand-out; no in-kernel threshold seeding
+constexpr unsigned DBG_OLD_QS = 0x10000u, DBG_MFMA32 = 0x20000u, DBG_MFMA16 = 0x40000u, DBG_NO_DYN = 0x80000u,
+                   DBG_NO_SEED = 0x100000u, DBG_PUB1 = 0x200000u;
 
 // n_lists, b_pad and pre_tiles depend on (B, n, k) only: mmrag_cosine_topk_select and the workspace query
 // have no dtype, so both kernels keep the same list layout
@@ -627,7 +631,7 @@ extern "C" {
 
 // workspace: [cand_s entries f32][cand_r entries i32][thr0 b_pad f32][sample top_s b_pad*K f32][pad][sample top_r b_pad*K i64]
 struct WsLayout {
-    size_t entries, off_r, off_thr, off_ts, off_tr, off_cnt, cnt_bytes, off_pub, total;
+    size_t entries, off_r, off_thr, off_ts, off_tr, off_cnt, cnt_bytes, off_pub, off_pthr, off_tk, xch_end, total;
 };
 static WsLayout ws_layout(const Plan &pl) {
     WsLayout w;
@@ -640,7 +644,12 @@ static WsLayout ws_layout(const Plan &pl) {
     w.off_cnt = (w.off_tr + (size_t)pl.b_pad * pl.K * sizeof(long long) + 63) / 64 * 64;
     w.cnt_bytes = 0;
     w.off_pub = w.off_cnt + w.cnt_bytes;
-    w.total = w.off_pub + (pl.qs_room ? (size_t)pl.b_pad * pl.grid_x * sizeof(float) : 0);
+    // single-launch walk: the exchange block [bests b_pad x walkers | thresholds b_pad | tickets per query group],
+    // filled with the bit pattern of -inf before every launch (the three-launch plan uses the first part only)
+    w.off_pthr = w.off_pub + (pl.qs_room ? (size_t)pl.b_pad * pl.grid_x * sizeof(float) : 0);
+    w.off_tk = w.off_pthr + (pl.qs_room ? (size_t)pl.b_pad * sizeof(float) : 0);
+    w.xch_end = w.off_tk + (pl.qs_room ? ((size_t)pl.grid_y * sizeof(unsigned) + 63) / 64 * 64 : 0);
+    w.total = w.xch_end;
     return w;
 }
 
@@ -696,12 +705,49 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
     p.tile0 = 0;
     p.thr0 = nullptr;
     p.dbg = dbg;
-    p.stamps = ((dbg & DBG_QS_CLOCK) && workspace_bytes >= wl.total + 64 * (size_t)(pl.grid_x * pl.grid_y)) ? (unsigned long long *)((char *)workspace + wl.total) : nullptr;
+    // (per workgroup: 8 words in the three-launch kernel, 32 in the walk kernel -- room for the larger)
+    p.stamps = ((dbg & DBG_QS_CLOCK) && workspace_bytes >= wl.total + 256 * (size_t)(pl.grid_x * pl.grid_y)) ? (unsigned long long *)((char *)workspace + wl.total) : nullptr;
     p.walkers = pl.grid_x;
     p.share_l2 = pl.grid_y > 1;
     p.sample_best = nullptr;
+    p.pub_best = nullptr;
+    p.pub_thr = nullptr;
+    p.tickets = nullptr;
+    p.p_static = INT_MAX / 2;
+    p.pub0 = 0;
     hipStream_t s = (hipStream_t)stream;
     const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the sample's list: last slot of every query
+    const int walk_mfma = (dbg & DBG_MFMA32) ? 32 : ((dbg & DBG_MFMA16) ? 16 : (pl.K == 5 ? QSW_DEFAULT_MFMA : 32));
+    if (pl.qs_ok && !(dbg & DBG_OLD_QS) && qsw_supported(dtype, p.row_bytes, pl.K, walk_mfma)) {
+        // single-launch walk (search_qsw.hip): thresholds are exchanged inside the launch through a block the host fills
+        // with -inf first; the last tenth of the tiles is handed out by ticket when there is one query group
+        const int tiles = (int)((n + QS_TILE_ROWS - 1) / QS_TILE_ROWS);
+        const int per = tiles / pl.grid_x;
+        p.n_tiles = tiles;
+        p.pub_best = nullptr;
+        p.pub_thr = nullptr;
+        p.tickets = nullptr;
+        p.p_static = INT_MAX / 2;
+        p.pub0 = (dbg & DBG_PUB1) ? 1 : 0;
+        const bool seed = per >= 12 && !(dbg & DBG_NO_SEED);
+        const bool dyn = pl.grid_y == 1 && per >= 24 && !(dbg & DBG_NO_DYN);
+        if (seed || dyn) {
+            MMRAG_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)((char *)workspace + wl.off_pub), (int)TICKET0,
+                                              (wl.xch_end - wl.off_pub) / 4, s));
+            if (seed) {
+                p.pub_best = (float *)((char *)workspace + wl.off_pub);
+                p.pub_thr = (float *)((char *)workspace + wl.off_pthr);
+            }
+            if (dyn) {
+                p.tickets = (unsigned *)((char *)workspace + wl.off_tk);
+                const int tail = per / 10 > 3 ? per / 10 : 3;
+                p.p_static = per - tail;   // >= 21
+            }
+        }
+        if (int st = qsw_launch(dtype, pl.K, walk_mfma, p, pl.grid_x, pl.grid_y, s)) return st;
+        MMRAG_CHECK_HIP(hipGetLastError());
+        return MMRAG_OK;
+    }
     if (pl.qs_ok && qs_supported(dtype, p.row_bytes, pl.K)) {
         // query-stationary kernel.  Long shards: (1) a sample pass over the first pre_tiles * 256 rows that keeps
         // only each workgroup's best score per query, (2) thr0[q] = K-th largest of those bests, (3) the walk over
@@ -767,7 +813,8 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
 int mmrag_internal_search_uses_qs(int B, int64_t n, int64_t ld, int dtype, int k) {
     if (B <= 0 || n <= 0 || k <= 0 || k > MMRAG_MAX_K) return 0;
     const Plan pl = make_plan(B, n, k, 0u);
-    return pl.qs_ok && qs_supported(dtype, (unsigned)(ld * esize(dtype)), pl.K) ? 1 : 0;
+    const unsigned rb = (unsigned)(ld * esize(dtype));
+    return pl.qs_ok && (qs_supported(dtype, rb, pl.K) || qsw_supported(dtype, rb, pl.K, 32)) ? 1 : 0;
 }
 
 int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,

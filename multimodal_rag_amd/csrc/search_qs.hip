@@ -98,37 +98,6 @@ __device__ __forceinline__ void qs_kstep(f32x16_t &c00, f32x16_t &c01, f32x16_t 
     }
 }
 
-// K-th largest of the (up to) 256 values a wave holds four per lane; every lane gets the result.  Used to turn the
-// per-workgroup best scores of one query into a threshold: the values are scores of distinct rows, so K rows reach it.
-template <int K>
-__device__ inline float wave_kth_largest(float a, float b, float c, float d, int lane) {
-    auto ce = [](float &x, float &y) {
-        const float hi = fmaxf(x, y), lo = fminf(x, y);
-        x = hi;
-        y = lo;
-    };
-    ce(a, b);
-    ce(c, d);
-    ce(a, c);
-    ce(b, d);
-    ce(b, c);  // a >= b >= c >= d
-    float res = NEG_INF;
-    for (int r = 0; r < K; ++r) {
-        float m = a;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        res = m;
-        const unsigned long long owners = __builtin_amdgcn_ballot_w64(a == m);
-        if (owners != 0ull && lane == (int)__builtin_ctzll(owners)) {  // one lane gives up its head
-            a = b;
-            b = c;
-            c = d;
-            d = NEG_INF;
-        }
-    }
-    return res;
-}
-
 template <int DT, int NK, int K, bool NT>
 __global__ __launch_bounds__(256, 1) void cosine_topk_qs_kernel(const KParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -76,11 +76,52 @@ struct KParams {
     unsigned long long *stamps;  // DBG_QS_CLOCK: per-workgroup (shader cycles, 100 MHz ticks) of the main loop
     float *sample_best;   // query-stationary kernel, sample pass: [b_pad][walkers] best score per query per workgroup
                           // (no candidate lists are written); null = a normal pass
+    // ---- single-launch walk kernel (search_qsw.hip) ----
+    float *pub_best;      // [query groups][walkers][256]: every workgroup's best score per query after its first tiles,
+                          // -inf until published (the host fills the exchange block with -inf before the launch);
+                          // null = no in-kernel threshold seeding
+    float *pub_thr;       // [query groups][256]: K-th largest of a query's published bests, -inf until computed
+    unsigned *tickets;    // [query groups]: next dynamically handed-out tile, counted from TICKET0
+    int pub0;             // tile after which a workgroup first publishes its bests (0 = after its first tile)
+    int p_static;         // tile positions every workgroup walks by the static rule (tile = bx + pos * walkers); the
+                          // tiles from p_static * walkers on are handed out by ticket.  Huge = no dynamic hand-out
 };
+constexpr unsigned TICKET0 = 0xff800000u;   // the exchange block is filled with the bit pattern of -inf
 
 // timing-only ablations of the query-stationary kernel: results are WRONG with any of them set
 constexpr unsigned DBG_QS_NO_SELECT = 16u, DBG_QS_NO_DMA = 32u, DBG_QS_NO_BARRIER = 64u, DBG_QS_DMA_L2 = 512u, DBG_QS_NO_WAIT = 1024u;
 constexpr unsigned DBG_QS_CLOCK = 256u;  // (valid results) first 16 workgroups stamp their main loop: clock under load
+
+// K-th largest of the (up to) 256 values a wave holds four per lane; every lane gets the result.  Used to turn the
+// per-workgroup best scores of one query into a threshold: the values are scores of distinct rows, so K rows reach it.
+template <int K>
+__device__ inline float wave_kth_largest(float a, float b, float c, float d, int lane) {
+    auto ce = [](float &x, float &y) {
+        const float hi = fmaxf(x, y), lo = fminf(x, y);
+        x = hi;
+        y = lo;
+    };
+    ce(a, b);
+    ce(c, d);
+    ce(a, c);
+    ce(b, d);
+    ce(b, c);  // a >= b >= c >= d
+    float res = NEG_INF;
+    for (int r = 0; r < K; ++r) {
+        float m = a;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        res = m;
+        const unsigned long long owners = __builtin_amdgcn_ballot_w64(a == m);
+        if (owners != 0ull && lane == (int)__builtin_ctzll(owners)) {  // one lane gives up its head
+            a = b;
+            b = c;
+            c = d;
+            d = NEG_INF;
+        }
+    }
+    return res;
+}
 
 // ---- query-stationary kernel (search_qs.hip) -------------------------------------------------------------
 // supported(): storage dtype, row bytes and list depth the kernel is instantiated for
@@ -91,6 +132,12 @@ constexpr int QS_QROWS = 256;      // queries per workgroup
 int qs_launch(int dtype, int K, const KParams &p, int grid_x, int grid_y, hipStream_t s);
 // thr0[q] = K-th largest of best[q][0 .. walkers): the threshold a sample pass yields
 int qs_seed_thresholds(int K, const float *best, int walkers, int n_queries, float *thr0, hipStream_t s);
+
+// ---- single-launch walk kernel (search_qsw.hip): same tiles and candidate lists, thresholds seeded inside the launch ---
+// mfma: 32 = v_mfma_f32_32x32x16, 16 = v_mfma_f32_16x16x32 (K = 5 only)
+constexpr int QSW_DEFAULT_MFMA = 16;   // the shape list depth 5 runs on (A/B in DESIGN.md section 7)
+bool qsw_supported(int dtype, unsigned row_bytes, int K, int mfma);
+int qsw_launch(int dtype, int K, int mfma, const KParams &p, int grid_x, int grid_y, hipStream_t s);
 
 
 }  // namespace mmrag_impl

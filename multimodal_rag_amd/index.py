@@ -331,8 +331,7 @@ class VectorIndex:
         """Ascending LIVE rows whose metadata matches `where` (inverted index when the form allows, else a scan)."""
         fast = self._meta_index.rows(where)
         if fast is None:
-            fast = np.fromiter((i for i in range(self._n)
-                                if self._ids[i] is not None and match_where(self._metadatas[i], where)), dtype=np.int64)
+            fast = np.fromiter((i for i in range(self._n) if match_where(self._metadatas[i], where)), dtype=np.int64)
         if self._n_dead and fast.size:
             fast = fast[~self._is_dead(fast)]
         return fast
@@ -402,7 +401,9 @@ class VectorIndex:
 
         The lock is held only while the kernels are enqueued: concurrent callers (asyncio.to_thread workers,
         embedder.py:595) overlap their host waits and result building.  Row tables are append-only between
-        compactions and a compaction swaps in NEW lists, so the snapshot taken under the lock stays valid."""
+        compactions (a delete only clears alive bits and the id map) and a compaction swaps in NEW lists, so the
+        snapshot taken under the lock stays valid: a hit whose row is deleted after the launch is still returned
+        whole, exactly as if the delete had come a moment later."""
         with self._lock, stage("search"):
             scores, rows = self._launch_search(query_embeddings, n_results, where, check_norm)
             ids_t, docs_t, metas_t = self._ids, self._documents, self._metadatas
@@ -478,10 +479,11 @@ class VectorIndex:
             if rows.size == 0:
                 return []
             gone = [self._ids[int(r)] for r in rows]
-            for r, s in zip(rows.tolist(), gone):
+            for s in gone:
                 del self._row_of[s]
-                self._ids[r] = None
-                self._documents[r] = None
+            # The row tables (_ids, _documents, _metadatas) are NOT touched: a query() that enqueued its search before
+            # this delete builds its result from them after dropping the lock, and must still find the hit's id and
+            # text there.  The alive bitmap and _row_of are what say "dead"; compact() drops the entries for good.
             self._clear_alive(rows)
             self._n_dead += int(rows.size)
             if self._n_dead >= self.COMPACT_MIN_DEAD and self._n_dead > self.COMPACT_DEAD_FRACTION * self._n:

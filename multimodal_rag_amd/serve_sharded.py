@@ -39,6 +39,7 @@ class ShardedEngine:
         if self._col is None:
             self._col = ShardedCollection(self._engine.new_collection(name, metadata), self._group, self._device,
                                           encode_fn=self._engine.encode, control_group=self._control)
+            self._col.start_keepalive(600.0)     # the control group's timeout is finite (main())
         else:                                # delete_all_documents re-creates the collection (embedder.py:670-678)
             self._col.reset()
         return self._col
@@ -62,12 +63,13 @@ def main(argv=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29544")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    # the control plane (command headers, ingest batches, winners' payload) runs on gloo with a timeout no idle
-    # period can reach: workers block in it between requests, and the RCCL group's watchdog (10 minutes by default)
-    # would abort them.  RCCL carries the per-query all-gather only.
+    # the control plane (command headers, ingest batches, winners' payload) runs on gloo: workers block in it between
+    # requests, and the RCCL group's watchdog (10 minutes by default) would abort them.  Its timeout is finite (a lost
+    # collective step must surface as an error, not hang rank 0 under the service lock for ever); rank 0 pings the
+    # workers every 10 idle minutes (ShardedCollection.start_keepalive).  RCCL carries the per-query all-gather only.
     import datetime
 
-    control = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=365))
+    control = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
     try:
         if rank == 0:
             import uvicorn

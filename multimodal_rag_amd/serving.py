@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import logging
 import threading
+import time
 from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -42,7 +43,7 @@ class ShardError(RuntimeError):
     """a rank's local step of a collection command failed; raised on rank 0 with every failing rank's message"""
 
 
-OP_STOP, OP_QUERY, OP_OBJECT = 0, 1, 2
+OP_STOP, OP_QUERY, OP_OBJECT, OP_PING = 0, 1, 2, 3
 _INCLUDE_BITS = {"distances": 1, "metadatas": 2, "documents": 4, "embeddings": 8}
 _FAILED_ROW = -2      # first sequence number of a rank's packed block when its local search raised
 
@@ -52,8 +53,9 @@ class ShardedCollection:
 
     * control (`control_group`, default = `group`): a fixed 8-word int64 header per command, and pickled objects
       only for what is not a tensor (ingest batches, get / delete arguments, `where` dicts, the winners' payload).
-      Give it a gloo group with a long timeout: workers block in it between requests, and a collective watchdog (the
-      default 10 minutes of an RCCL group) would abort an idle service.
+      Give it a gloo group whose timeout is longer than the keep-alive interval (`start_keepalive`): workers block in
+      it between requests, and a collective watchdog (the default 10 minutes of an RCCL group) would abort an idle
+      service; with the keep-alive a finite timeout (hours) still turns a lost collective step into an error.
     * data (`group`, buffers on `device`): a query = header + the [B, d] float32 query matrix as a tensor broadcast,
       ONE all-gather of the packed per-rank candidates, the C++ host merge.  Nothing is pickled on that path.
 
@@ -90,9 +92,13 @@ class ShardedCollection:
         # the embedder calls the collection from asyncio.to_thread workers (embedder.py:517, 595): one
         # command (= one sequence of collectives) at a time per communicator
         self._lock = threading.Lock()
+        self._last_header = time.monotonic()      # rank 0: when the workers last heard from it
+        self._keepalive: Optional[threading.Thread] = None
+        self._stopped = threading.Event()
 
     # ------------------------------------------------------------------ control plane -------
     def _header(self, words: Optional[Sequence[int]]) -> List[int]:
+        self._last_header = time.monotonic()
         t = torch.zeros(8, dtype=torch.int64, device=self._ctl_device)
         if words is not None:
             t[: len(words)] = torch.tensor(list(words), dtype=torch.int64)
@@ -122,6 +128,8 @@ class ShardedCollection:
             hdr = self._header(None)
             if hdr[0] == OP_STOP:
                 return
+            if hdr[0] == OP_PING:
+                continue
             try:
                 if hdr[0] == OP_QUERY:
                     self._query_path(hdr, None, None)
@@ -132,8 +140,35 @@ class ShardedCollection:
 
     def stop(self):
         self._require_rank0()
+        self._stopped.set()
         with self._lock:
             self._header([OP_STOP])
+
+    def ping(self):
+        """rank 0: a header nobody acts on; resets the workers' wait in the control group"""
+        self._require_rank0()
+        with self._lock:
+            if not self._stopped.is_set():
+                self._header([OP_PING])
+
+    def start_keepalive(self, interval_s: float = 600.0):
+        """rank 0: ping the workers whenever the service has been idle for `interval_s`, so that the control group can
+        have a finite timeout (a lost collective step then surfaces as an error instead of a hang for ever)"""
+        self._require_rank0()
+        if self._keepalive is not None:
+            return
+
+        def loop():
+            while not self._stopped.wait(min(interval_s / 4.0, 30.0)):
+                if time.monotonic() - self._last_header >= interval_s:
+                    try:
+                        self.ping()
+                    except Exception:   # noqa: BLE001 -- the next real command will report the broken group
+                        logger.exception("keep-alive ping failed")
+                        return
+
+        self._keepalive = threading.Thread(target=loop, name="mmrag-shard-keepalive", daemon=True)
+        self._keepalive.start()
 
     def _execute(self, cmd: Dict[str, Any]):
         """local step on this rank -> one status gather -> finish on rank 0"""
@@ -302,29 +337,42 @@ class ShardedCollection:
             if self.rank != 0:
                 return None
             raise ShardError("query failed on " + "; ".join(f"rank {g}: {m}" for g, m in enumerate(msgs) if m))
-        with stage("shard.merge"):
-            if k <= _native.MAX_K:
-                top_s, top_r = _native.merge_topk_host_packed(host, self.world, B, k, k)
-                top_s, top_r = top_s.numpy(), top_r.numpy()
-            else:
-                top_s, top_r = _merge_deep(host, self.world, B, k)
-        # describe the winning rows this rank owns (the only pickled part of a query: k rows' payload per query)
+        # Merge and payload: a rank that raises here (a payload fetch is a GPU call for include=embeddings) must still
+        # take part in the payload gather, or rank 0 waits in it for ever while holding the service lock.  Every rank
+        # gathers an (ok, payload-or-message) pair, as `_execute` does for the other commands.
         mine: Dict[int, Dict[str, Any]] = {}
-        owned = sorted({int(sq) for sq in top_r.reshape(-1) if sq >= 0 and int(sq) in self._id_of})
-        if owned:
-            got = self.shard.get(ids=[self._id_of[sq] for sq in owned],
-                                 include=tuple(x for x in include if x != "distances"))
-            at = {i: j for j, i in enumerate(got["ids"])}
-            for sq in owned:
-                j = at[self._id_of[sq]]
-                mine[sq] = {"id": self._id_of[sq],
-                            "metadata": got["metadatas"][j] if got.get("metadatas") is not None else None,
-                            "document": got["documents"][j] if got.get("documents") is not None else None,
-                            "embedding": got["embeddings"][j] if got.get("embeddings") is not None else None}
+        failure = None
+        top_s = top_r = None
+        try:
+            with stage("shard.merge"):
+                if k <= _native.MAX_K:
+                    top_s, top_r = _native.merge_topk_host_packed(host, self.world, B, k, k)
+                    top_s, top_r = top_s.numpy(), top_r.numpy()
+                else:
+                    top_s, top_r = _merge_deep(host, self.world, B, k)
+            # describe the winning rows this rank owns (the only pickled part of a query: k rows' payload per query)
+            owned = sorted({int(sq) for sq in top_r.reshape(-1) if sq >= 0 and int(sq) in self._id_of})
+            if owned:
+                got = self.shard.get(ids=[self._id_of[sq] for sq in owned],
+                                     include=tuple(x for x in include if x != "distances"))
+                at = {i: j for j, i in enumerate(got["ids"])}
+                for sq in owned:
+                    j = at[self._id_of[sq]]
+                    mine[sq] = {"id": self._id_of[sq],
+                                "metadata": got["metadatas"][j] if got.get("metadatas") is not None else None,
+                                "document": got["documents"][j] if got.get("documents") is not None else None,
+                                "embedding": got["embeddings"][j] if got.get("embeddings") is not None else None}
+        except Exception as e:   # noqa: BLE001 -- reported through the gather below, the rank stays in step
+            logger.exception("rank %d: building the query payload failed", self.rank)
+            failure = f"{type(e).__name__}: {e}"
         with stage("shard.payload"):
-            payloads = self._gather(mine)
+            answers = self._gather((failure is None, mine if failure is None else failure))
         if self.rank != 0:
             return None
+        bad = [(g, a[1]) for g, a in enumerate(answers) if not a[0]]
+        if bad:
+            raise ShardError("query failed on " + "; ".join(f"rank {g}: {m}" for g, m in bad))
+        payloads = [a[1] for a in answers]
         out: Dict[str, Any] = {"ids": []}
         for key in ("distances", "metadatas", "documents", "embeddings"):
             out[key] = [] if key in include else None

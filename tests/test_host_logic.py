@@ -347,3 +347,34 @@ def test_stage_timers_and_stats_key(monkeypatch):
     assert "unit.a" in m.get_stage_timers()
     tracing.reset()
     assert tracing.snapshot() == {}
+
+
+def test_delete_between_search_launch_and_result_building_keeps_hits_whole():
+    """ADVICE r2: query() drops the index lock after enqueueing the kernels and builds its result from the row tables;
+    a delete() landing in between used to blank `_ids[r]` / `_documents[r]` in place, so the result carried id None
+    (and `retriever._item_id_to_redis_key(None)` raised -> HTTP 500).  The tables now stay whole until compaction.
+    Host tables only: the index lives on the CPU device here, no kernel is called."""
+    import numpy as np
+    import torch
+    from multimodal_rag_amd.index import VectorIndex
+
+    ix = VectorIndex(dim=8, dtype=torch.float32, device="cpu")
+    ids = [f"doc_a_text_{i}" for i in range(6)]
+    rows = torch.zeros((6, ix.ld), dtype=torch.float32)
+    rows[:, 0] = 1.0
+    ix.add_rows_device(rows, [f"text {i}" for i in range(6)], [{"doc_id": "doc_a", "type": "text"} for _ in ids], ids)
+    # what query() holds when it leaves the lock: device results (here: rows 1, 4 and a miss) and the table snapshot
+    scores = torch.tensor([[0.9, 0.8, float("-inf")]])
+    hit_rows = torch.tensor([[1, 4, -1]], dtype=torch.int64)
+    snap = (ix._ids, ix._documents, ix._metadatas)
+    assert ix.delete(ids=[ids[1]]) == [ids[1]]            # lands before the result is built
+    out = ix._collect(scores, hit_rows, ("metadatas", "documents", "distances"), *snap, None)
+    assert out["ids"] == [[ids[1], ids[4]]] and None not in out["ids"][0]
+    assert out["documents"] == [["text 1", "text 4"]]
+    assert out["metadatas"][0][0]["doc_id"] == "doc_a"
+    # the row is dead for everything that starts after the delete
+    assert ix.count() == 5 and ids[1] not in ix._row_of
+    assert ix.get(ids=[ids[1]])["ids"] == []
+    assert ids[1] not in ix.get(where={"doc_id": "doc_a"})["ids"]
+    assert ix._rows_where({"$or": [{"doc_id": "doc_a"}, {"type": "text"}]}).tolist() == [0, 2, 3, 4, 5]   # scan fallback
+    # (compact() moves rows with a HIP kernel: tests/test_pipeline_gpu.py covers it)

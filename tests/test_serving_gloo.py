@@ -190,6 +190,12 @@ class FlakyCollection(FakeCollection):
             raise MemoryError("shard is full")
         return super().add(embeddings, documents, metadatas, ids)
 
+    def get(self, ids=None, where=None, include=("metadatas", "documents")):
+        # the payload step of a query (after the all-gather): include=embeddings is a GPU fetch on a real index
+        if "embeddings" in include and getattr(self, "payload_boom", False):
+            raise RuntimeError("fetch_rows failed")
+        return super().get(ids=ids, where=where, include=include)
+
 
 def _flaky_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -200,7 +206,10 @@ def _flaky_worker(rank, world, port, out_dir):
 
         shard = FlakyCollection(D)
         shard.rank_tag = rank
-        col = ShardedCollection(shard, control_group=dist.new_group(backend="gloo"))
+        shard.payload_boom = rank == 1        # the worker's payload step of an include=embeddings query raises
+        import datetime
+
+        col = ShardedCollection(shard, control_group=dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60)))
         if rank != 0:
             col.worker_loop()
             return
@@ -208,6 +217,18 @@ def _flaky_worker(rank, world, port, out_dir):
         col.add(v[:80].tolist(), documents=docs[:80], metadatas=metas[:80], ids=ids[:80])
         good = col.query(q.tolist(), n_results=5)
         out = {}
+        # a worker raising AFTER the all-gather (merge / payload) used to skip the payload gather and leave
+        # rank 0 waiting in it for ever; now it reports, rank 0 raises, and the service goes on
+        try:
+            col.query(q.tolist(), n_results=5, include=("embeddings", "distances"))
+            out["payload"] = "no error"
+        except ShardError as e:
+            out["payload"] = str(e)
+        out["after_payload"] = col.query(q.tolist(), n_results=5) == good
+        col.start_keepalive(0.2)              # idle pings: the workers just keep waiting
+        import time as _t
+        _t.sleep(0.8)
+        out["after_pings"] = col.query(q.tolist(), n_results=5) == good
         for bad_rank in (0, 1):              # the driving rank's shard fails / a worker's shard fails
             try:
                 col.query(q.tolist(), n_results=5, where={"boom": bad_rank})
@@ -254,6 +275,8 @@ def test_failing_rank_reports_and_service_survives(tmp_path):
     assert "rank 0: ValueError" in out["query_0"] and "rank 1" not in out["query_0"]
     assert "rank 1: ValueError" in out["query_1"]
     assert out["after_query_0"] and out["after_query_1"]
+    assert "rank 1: RuntimeError: fetch_rows failed" in out["payload"] and "rank 0" not in out["payload"]
+    assert out["after_payload"] and out["after_pings"]
     assert "rank 1: MemoryError" in out["add"]
     assert out["count_after_failed_add"] == 0           # the half-stored batch was taken out again
     assert out["count_after_retry"] == 8 and out["retry_rows_found"]

@@ -1,0 +1,39 @@
+"""First-light check of the single-launch walk kernel against the three-launch plan and torch, several shapes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_rag_amd import _native as N
+torch.manual_seed(1)
+d, k, dtype = 768, 5, torch.float16
+ld = N.padded_dim(d, dtype)
+def mk(n, B, integer=False):
+    if integer:   # small integers: exact in fp16/fp32, many ties
+        c = torch.randint(-3, 4, (n, ld), device="cuda").to(dtype); q = torch.randint(-3, 4, (B, ld), device="cuda").to(dtype)
+    else:
+        c = torch.randn((n, ld), device="cuda"); c = (c / c.norm(dim=1, keepdim=True)).to(dtype)
+        q = torch.randn((B, ld), device="cuda"); q = (q / q.norm(dim=1, keepdim=True)).to(dtype)
+    return q, c
+def ref(q, c, n):
+    s = (q.float() @ c[:n].float().T)
+    # ties -> lower row: sort by (-score, row)
+    v, i = torch.sort(s, dim=1, descending=True, stable=True)
+    return v[:, :k], i[:, :k]
+ok = True
+for (n, B, integer) in [(400_000, 256, False), (400_000, 200, True), (399_937, 256, False), (1_000_000, 256, False), (500_000, 300, False)]:
+    q, c = mk(n, B, integer)
+    rs, rr = ref(q, c, n)
+    for name, f in [("old", N.DBG_OLD_QS), ("m16", N.DBG_MFMA16), ("m32", N.DBG_MFMA32), ("m16+nodyn", N.DBG_MFMA16 | N.DBG_NO_DYN),
+                    ("m16+noseed", N.DBG_MFMA16 | N.DBG_NO_SEED), ("m32+nodyn+noseed", N.DBG_MFMA32 | N.DBG_NO_DYN | N.DBG_NO_SEED)]:
+        s_, r_ = N.cosine_topk(q, c, n, d, k, dbg=f | N.DBG_FORCE_QS)
+        torch.cuda.synchronize()
+        if integer:
+            good = torch.equal(r_, rr) and torch.equal(s_, rs)
+        else:
+            good = torch.equal(r_, rr) and (s_ - rs).abs().max().item() < 2e-5
+        ok &= good
+        print(f"n={n} B={B} int={integer} {name:18s} {'OK' if good else 'MISMATCH'}  rows_equal={torch.equal(r_, rr)} max|ds|={(s_-rs).abs().max().item():.2e}", flush=True)
+        if not good:
+            bad = (r_ != rr).any(dim=1).nonzero().flatten()[:5].tolist()
+            print("   first bad queries", bad, r_[bad[:1]].tolist() if bad else None, rr[bad[:1]].tolist() if bad else None)
+print("ALL OK" if ok else "FAILED")
+sys.exit(0 if ok else 1)
