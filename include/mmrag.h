@@ -216,12 +216,20 @@ int mmrag_resize_crop_u8(const uint8_t *src, int H, int W, int64_t src_row_bytes
  * micro-benchmark peak, fractions against both the vendor and the measured peaks").  Not on the product path.
  *   mmrag_device_info        CU count, maximum shader clock (MHz), HBM bytes of the current device
  *   mmrag_bench_stream_copy  one 16-byte-per-lane copy of `bytes` bytes dst <- src (time it with events: moves 2 x bytes)
+ *   mmrag_bench_stream_read  read-only stream: every lane loads 16 bytes per step (non-temporal) and sums them; one
+ *                            float per thread goes to `out` (dev, 8 x 256 floats per CU).  The READ peak a scan of
+ *                            the corpus is measured against (half of a copy's rate is not one).
+ *   mmrag_bench_stream_write write-only stream: 16-byte non-temporal stores of a constant over `bytes` bytes
  *   mmrag_bench_mfma_f16     `iters` x 4 back-to-back v_mfma_f32_32x32x16_f16 per wave, one wave per SIMD on every CU,
  *                            operands from `seed` (dev, 256 x 16 bytes of fp16 data; use random values: the clock the
- *                            chip holds depends on them); `out` dev, 256 floats per CU; *flops = work of one launch */
+ *                            chip holds depends on them); `out` dev, 256 floats per CU; *flops = work of one launch
+ *   mmrag_bench_mfma_f16_16x16x32  the same output tile per wave (64 x 64) on v_mfma_f32_16x16x32_f16: 16 per step */
 int mmrag_device_info(int *n_cus, int *max_clock_mhz, int64_t *hbm_bytes);
 int mmrag_bench_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
+int mmrag_bench_stream_read(const void *src, int64_t bytes, float *out, void *stream);
+int mmrag_bench_stream_write(void *dst, int64_t bytes, void *stream);
 int mmrag_bench_mfma_f16(const void *seed, float *out, int iters, int64_t *flops, void *stream);
+int mmrag_bench_mfma_f16_16x16x32(const void *seed, float *out, int iters, int64_t *flops, void *stream);
 
 /* The encoder's building blocks, exported so each kernel can be parity-tested on its own. */
 int mmrag_linear_f16(const void *x, int64_t M, int K, const void *wt, int N, const float *bias, int act,

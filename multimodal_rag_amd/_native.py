@@ -69,6 +69,12 @@ def _declare(lib):
     lib.mmrag_bench_stream_copy.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     lib.mmrag_bench_mfma_f16.restype = c_int
     lib.mmrag_bench_mfma_f16.argtypes = [c_void_p, c_void_p, c_int, ctypes.POINTER(c_int64), c_void_p]
+    lib.mmrag_bench_mfma_f16_16x16x32.restype = c_int
+    lib.mmrag_bench_mfma_f16_16x16x32.argtypes = [c_void_p, c_void_p, c_int, ctypes.POINTER(c_int64), c_void_p]
+    lib.mmrag_bench_stream_read.restype = c_int
+    lib.mmrag_bench_stream_read.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    lib.mmrag_bench_stream_write.restype = c_int
+    lib.mmrag_bench_stream_write.argtypes = [c_void_p, c_int64, c_void_p]
     lib.mmrag_copy_to_host_async.restype = c_int
     lib.mmrag_copy_to_host_async.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.mmrag_encoder_workspace_bytes.restype = c_size_t
@@ -140,8 +146,14 @@ def _dev_check(*tensors):
 
 
 def search_uses_query_stationary(B: int, n: int, d: int, k: int, dtype: torch.dtype) -> bool:
-    """which kernel a search of this shape runs on (True: cosine_topk_qs_kernel, False: the slab-ring cosine_topk_kernel)"""
+    """which kernel a search of this shape runs on (True: a query-stationary kernel, False: the slab-ring cosine_topk_kernel)"""
     return bool(lib().mmrag_internal_search_uses_qs(B, n, padded_dim(d, dtype), _TORCH2DT[dtype], k))
+
+
+def search_kernel_name(B: int, n: int, d: int, k: int, dtype: torch.dtype) -> str:
+    """name of the dominant kernel of a search of this shape (for the bench's roofline label)"""
+    v = lib().mmrag_internal_search_uses_qs(B, n, padded_dim(d, dtype), _TORCH2DT[dtype], k)
+    return {0: "cosine_topk_kernel (slab-ring)", 1: "cosine_topk_qs_kernel", 2: "cosine_topk_walk_kernel"}[v]
 
 
 def padded_dim(d: int, dtype: torch.dtype) -> int:
@@ -237,8 +249,12 @@ def measure_peaks(device: torch.device, seconds: float = 0.4) -> dict:
 
         t = timed(lambda: _check(L.mmrag_bench_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, stream), "copy"), seconds)
         out["stream_copy_GBps"] = round(2 * nbytes / t / 1e9, 1)      # bytes read + bytes written
-        out["stream_copy_read_GBps"] = round(nbytes / t / 1e9, 1)
-        del src, dst
+        sink = torch.empty(256 * 8 * 256, dtype=torch.float32, device=device)
+        t = timed(lambda: _check(L.mmrag_bench_stream_read(src.data_ptr(), nbytes, sink.data_ptr(), stream), "read"), seconds)
+        out["stream_read_GBps"] = round(nbytes / t / 1e9, 1)           # a read-only stream: what a corpus scan is
+        t = timed(lambda: _check(L.mmrag_bench_stream_write(dst.data_ptr(), nbytes, stream), "write"), seconds)
+        out["stream_write_GBps"] = round(nbytes / t / 1e9, 1)
+        del src, dst, sink
         seed = (torch.randn(256 * 8, device=device) * 0.5).to(torch.float16)
         res = torch.empty(256 * 1024, dtype=torch.float32, device=device)
         flops = c_int64(0)
@@ -246,6 +262,10 @@ def measure_peaks(device: torch.device, seconds: float = 0.4) -> dict:
         t = timed(lambda: _check(L.mmrag_bench_mfma_f16(seed.data_ptr(), res.data_ptr(), iters, ctypes.byref(flops), stream),
                                  "mfma"), seconds)
         out["mfma_f16_TFLOPs"] = round(flops.value / t / 1e12, 1)
+        iters = 5000
+        t = timed(lambda: _check(L.mmrag_bench_mfma_f16_16x16x32(seed.data_ptr(), res.data_ptr(), iters,
+                                                                 ctypes.byref(flops), stream), "mfma16"), seconds)
+        out["mfma_f16_16x16x32_TFLOPs"] = round(flops.value / t / 1e12, 1)
     return out
 
 

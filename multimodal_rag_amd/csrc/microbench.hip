@@ -17,6 +17,28 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(u32x4_t *__restrict__ 
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// read-only: the sum keeps the loads alive; one store per thread at the end
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4_t *__restrict__ src, long long n_vec,
+                                                          float *__restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    u32x4_t acc = {0u, 0u, 0u, 0u};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+        const u32x4_t v = __builtin_nontemporal_load(src + i);
+        acc.x ^= v.x;
+        acc.y ^= v.y;
+        acc.z ^= v.z;
+        acc.w ^= v.w;
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = __uint_as_float((acc.x ^ acc.y ^ acc.z ^ acc.w) & 0x3fffffffu);
+}
+
+__global__ __launch_bounds__(256) void stream_write_kernel(u32x4_t *__restrict__ dst, long long n_vec) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const u32x4_t v = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride)
+        __builtin_nontemporal_store(v, dst + i);
+}
+
 // Back-to-back v_mfma_f32_32x32x16_f16 on four independent accumulators per wave, operands from `seed` (random data:
 // the clock the chip holds under an MFMA load depends on the operand values, so zeros would flatter the peak).
 // One wave per SIMD at 256 threads per workgroup and one workgroup per CU.
@@ -35,6 +57,32 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(const half8_t *__restric
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s += c0[j] + c1[j] + c2[j] + c3[j];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+#endif
+}
+
+// the same 64 x 64 output tile per wave on the 16x16x32 shape: 4 A x 4 B fragments, sixteen accumulators of 4.  Which
+// shape the chip clocks higher under load is measured, not assumed (MI355X_MICROARCH.md, DVFS give-back item 7)
+__global__ __launch_bounds__(256) void mfma_peak16_kernel(const half8_t *__restrict__ seed, float *__restrict__ out,
+                                                          int iters) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63;
+    half8_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = seed[(i * 64 + lane) & 255];
+        b[i] = seed[((i + 1) * 64 + 17 * lane) & 255];
+    }
+    f32x4_t c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i >> 2], b[i & 3], c[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 #endif
 }
@@ -60,6 +108,31 @@ int mmrag_bench_stream_copy(void *dst, const void *src, int64_t bytes, void *str
     MMRAG_CHECK_ARG(((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0, "bench_stream_copy: 16-byte alignment");
     stream_copy_kernel<<<num_cus() * 8, 256, 0, (hipStream_t)stream>>>((u32x4_t *)dst, (const u32x4_t *)src, bytes / 16);
     MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_bench_stream_read(const void *src, int64_t bytes, float *out, void *stream) {
+    MMRAG_CHECK_ARG(src && out && bytes > 0 && bytes % 16 == 0, "bench_stream_read: need 16-byte multiples");
+    MMRAG_CHECK_ARG(((uintptr_t)src % 16) == 0, "bench_stream_read: 16-byte alignment");
+    stream_read_kernel<<<num_cus() * 8, 256, 0, (hipStream_t)stream>>>((const u32x4_t *)src, bytes / 16, out);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_bench_stream_write(void *dst, int64_t bytes, void *stream) {
+    MMRAG_CHECK_ARG(dst && bytes > 0 && bytes % 16 == 0, "bench_stream_write: need 16-byte multiples");
+    MMRAG_CHECK_ARG(((uintptr_t)dst % 16) == 0, "bench_stream_write: 16-byte alignment");
+    stream_write_kernel<<<num_cus() * 8, 256, 0, (hipStream_t)stream>>>((u32x4_t *)dst, bytes / 16);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    return MMRAG_OK;
+}
+
+int mmrag_bench_mfma_f16_16x16x32(const void *seed, float *out, int iters, int64_t *flops, void *stream) {
+    MMRAG_CHECK_ARG(seed && out && iters > 0, "bench_mfma_f16_16x16x32: bad arguments");
+    const int grid = num_cus();
+    mfma_peak16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half8_t *)seed, out, iters);
+    MMRAG_CHECK_HIP(hipGetLastError());
+    if (flops) *flops = (int64_t)grid * 4 /*waves*/ * (int64_t)iters * 16 /*MFMAs*/ * (2LL * 16 * 16 * 32);
     return MMRAG_OK;
 }
 

@@ -518,7 +518,7 @@ constexpr unsigned DBG_NO_PREPASS = 1u, DBG_8_WAVES = 2u, DBG_NO_QS = 4u, DBG_FO
 // query-stationary shapes: the three-launch plan of search_qs.hip instead of the single-launch walk (A/B, tests); the
 // walk's MFMA shape forced to 32x32x16 / 16x16x32; no dynamic tile hand-out; no in-kernel threshold seeding
 constexpr unsigned DBG_OLD_QS = 0x10000u, DBG_MFMA32 = 0x20000u, DBG_MFMA16 = 0x40000u, DBG_NO_DYN = 0x80000u,
-                   DBG_NO_SEED = 0x100000u, DBG_PUB1 = 0x200000u;
+                   DBG_NO_SEED = 0x100000u;
 
 // n_lists, b_pad and pre_tiles depend on (B, n, k) only: mmrag_cosine_topk_select and the workspace query
 // have no dtype, so both kernels keep the same list layout
@@ -714,7 +714,6 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
     p.pub_thr = nullptr;
     p.tickets = nullptr;
     p.p_static = INT_MAX / 2;
-    p.pub0 = 0;
     hipStream_t s = (hipStream_t)stream;
     const size_t seed_off = (size_t)(pl.n_lists - 1) * pl.K;  // the sample's list: last slot of every query
     const int walk_mfma = (dbg & DBG_MFMA32) ? 32 : ((dbg & DBG_MFMA16) ? 16 : (pl.K == 5 ? QSW_DEFAULT_MFMA : 32));
@@ -728,7 +727,6 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
         p.pub_thr = nullptr;
         p.tickets = nullptr;
         p.p_static = INT_MAX / 2;
-        p.pub0 = (dbg & DBG_PUB1) ? 1 : 0;
         const bool seed = per >= 12 && !(dbg & DBG_NO_SEED);
         const bool dyn = pl.grid_y == 1 && per >= 24 && !(dbg & DBG_NO_DYN);
         if (seed || dyn) {
@@ -808,13 +806,16 @@ int mmrag_internal_cosine_topk_lists_ex(const void *q, const void *corpus, int B
     return MMRAG_OK;
 }
 
-// which kernel a (B, n, ld, dtype, k) search runs on: 1 = query-stationary (search_qs.hip), 0 = slab-ring.  For the
+// which kernel a (B, n, ld, dtype, k) search runs on: 2 = single-launch walk (search_qsw.hip), 1 = three-launch
+// query-stationary (search_qs.hip), 0 = slab-ring.  For the
 // bench's roofline label and the tools; not part of the public ABI.
 int mmrag_internal_search_uses_qs(int B, int64_t n, int64_t ld, int dtype, int k) {
     if (B <= 0 || n <= 0 || k <= 0 || k > MMRAG_MAX_K) return 0;
     const Plan pl = make_plan(B, n, k, 0u);
     const unsigned rb = (unsigned)(ld * esize(dtype));
-    return pl.qs_ok && (qs_supported(dtype, rb, pl.K) || qsw_supported(dtype, rb, pl.K, 32)) ? 1 : 0;
+    if (!pl.qs_ok) return 0;
+    if (qsw_supported(dtype, rb, pl.K, QSW_DEFAULT_MFMA)) return 2;   // the single-launch walk (search_qsw.hip)
+    return qs_supported(dtype, rb, pl.K) ? 1 : 0;
 }
 
 int mmrag_cosine_topk_lists(const void *q, const void *corpus, int B, int64_t n, int d, int64_t ld, int dtype,

@@ -186,8 +186,13 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
     static_assert((NST - 1) * PPS <= 56, "vmcnt range");
     static_assert((G - 1) * SLABB + 48 * SLAB + 2048 < 65536, "ds_read immediate offset");
     static_assert(2 * PPS == KSTG, "one piece after every other statement");
-    // what one wave issues at a tile boundary has landed at the last hand-over wait of the next tile
-    static_assert(SPT * PPS - 1 >= (NST - 2) * PPS, "exchange pieces land within one tile");
+    // Exchange fetches (LDS-DMA, one wave) are issued at the end of a tile and used at the end of a later one: they
+    // have landed once the wave has passed NST - 2 hand-over waits with nothing but ring pieces in between, i.e.
+    // LANDT tiles later (1 for 768-d rows; short rows make a tile only one or two ring stages).  Issuing them among the
+    // k-steps (right after a hand-over, used at the end of the same tile: thresholds a tile earlier) was built too:
+    // hipcc's register allocation there does not survive any extra code, it spilled Q fragments into the tile loop.
+    constexpr int LANDT = ((NST - 2) * PPS + 1 + SPT * PPS - 1) / (SPT * PPS);
+    static_assert(LANDT >= 1 && LANDT * SPT * PPS - 1 >= (NST - 2) * PPS, "exchange pieces land before they are used");
     static_assert(LOOK <= 6, "ticket slots");
 
     __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE + LISTS + QSW_XCH];
@@ -354,21 +359,44 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
         });
         float t = thr[qb];
         if (__builtin_amdgcn_ballot_w64(mx >= t) == 0ull) return;
-        TopList<K> L;
+        // Which of this lane's NE scores reach its threshold.  While the thresholds are cold almost every element has
+        // SOME lane of the wave above its threshold, but a lane has only a few: walking the elements (below, `dense`)
+        // pays an insertion per element, walking each lane's own hits pays one per round of the slowest lane.
+        constexpr int NE = NGRP * 4;
+        // A lane that has no threshold yet (the first tiles of the walk) would pass every score.  Only its K best of
+        // this tile can enter its list: raise the bar to (a lower bound of) the K-th largest of the lane's NE scores --
+        // K rounds of "largest score below the last one" (equal scores count once: the bar only gets lower), trees of
+        // independent max operations: issue-bound, where insertions are latency-bound, and three live registers (a
+        // sorting network on copies was faster still but took sixteen, and hipcc then spilled a Q fragment).
+        // Scores equal to the bar still pass and are settled in row order by the insertions.
+        float bar = t;
+        if (__builtin_amdgcn_ballot_w64(t == NEG_INF) != 0ull) {
+            float prev = INFINITY;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                float m = NEG_INF;
+                static_for<NGRP>([&](auto gi_c) {
+                    const float x0 = score(qb_c, gi_c, 0), x1 = score(qb_c, gi_c, 1);
+                    const float x2 = score(qb_c, gi_c, 2), x3 = score(qb_c, gi_c, 3);
+                    const float y0 = x0 < prev ? x0 : NEG_INF, y1 = x1 < prev ? x1 : NEG_INF;
+                    const float y2 = x2 < prev ? x2 : NEG_INF, y3 = x3 < prev ? x3 : NEG_INF;
+                    m = fmaxf(m, fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
+                });
+                prev = m;
+            }
+            bar = fmaxf(t, prev);
+        }
+        unsigned mask = 0;
+        static_for<NE>([&](auto e_c) {
+            constexpr int e = decltype(e_c)::value;
+            mask |= score(qb_c, std::integral_constant<int, e / 4>{}, e % 4) >= bar ? (1u << e) : 0u;
+        });
+        TopList<K> L;   // (loaded only now: the network above wants the registers)
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             L.v[i] = lst_v(qb, i);
             L.r[i] = lst_r(qb, i);
         }
-        // Which of this lane's NE scores reach its threshold.  While the thresholds are cold almost every element has
-        // SOME lane of the wave above its threshold, but a lane has only a few: walking the elements (below, `dense`)
-        // pays an insertion per element, walking each lane's own hits pays one per round of the slowest lane.
-        constexpr int NE = NGRP * 4;
-        unsigned mask = 0;
-        static_for<NE>([&](auto e_c) {
-            constexpr int e = decltype(e_c)::value;
-            mask |= score(qb_c, std::integral_constant<int, e / 4>{}, e % 4) >= t ? (1u << e) : 0u;
-        });
         constexpr int DENSE_AT = NE == 16 ? 8 : 12;
         if (__builtin_amdgcn_ballot_w64(__builtin_popcount(mask) > DENSE_AT) == 0ull) {
             while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
@@ -389,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
                 const float sc = lvl[0];
                 const int row = MS == 32 ? (int)(((e >> 4) << 5) + (((e >> 2) & 3u) << 3) + (e & 3u))
                                          : (int)(((e >> 2) << 4) + (e & 3u));
-                L.insert_strict(valid && sc >= t ? sc : NEG_INF, row_base + row);
+                L.insert_strict_flat(valid && sc >= t ? sc : NEG_INF, row_base + row);
                 t = fmaxf(t, L.v[K - 1]);
             }
         } else {
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(p.pub_best + (size_t)by * walkers * QS_QROWS), 0, (unsigned)(walkers * QS_QROWS * 4), 0x00020000);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)   // (walkers past the group's last: out of the descriptor's range, nothing fetched)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((char *)gather_lds + c * 256), 4,
                                                      (unsigned)(((c * 64 + ln) * QS_QROWS + q) * 4), 0, 0, CP_SC1);
     };
@@ -468,11 +496,14 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
             thr[qb] = fmaxf(thr[qb], poll_lds[wave * 64 + qb * QW + ql]);
         });
     };
-    // two rounds: bests after tile PUB0 (the first tiles of every workgroup are the sample) and again after tile pub1
-    // (stragglers, and a sample several times as big); thresholds are polled every tile while they are fresh, every fourth tile afterwards
-    const int PUB0 = p.pub0;
-    const int pub1 = PUB0 + n_resp + 3;
-    auto polled_at = [&](int t) -> bool { return t >= PUB0 + 2 && (t < pub1 + n_resp + 6 || (t & 3) == 3); };
+    // Two rounds: bests after the first tile (a 64-row sample per workgroup) and again after tile pub1 (stragglers, and
+    // lists that have seen several tiles).  The responsible wave fetches the bests of its j-th query STEP tiles apart,
+    // starting the tile after the publication, and reduces them LANDT tiles later; thresholds are polled every tile
+    // while the rounds are fresh, every fourth tile afterwards.
+    constexpr int STEP = LANDT;
+    const int span = n_resp * STEP + LANDT + 1;     // tiles a round keeps the gather buffer busy
+    const int pub1 = span + 1 > 5 ? span + 1 : 5;
+    auto polled_at = [&](int t) -> bool { return t >= 1 + LANDT && (t < pub1 + span + 4 || (t & 3) == 3); };
 
     // ---- main loop.  One continuous software pipeline over statements: statement s issues the LDS reads of
     // statement s+1 (which may belong to the next ring stage or the next tile) before its own MFMAs.  The stage
@@ -585,14 +616,18 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
                 }
             }
             if (seeding) {
-                if (polled_at(ti - 1)) poll_consume(ql_t);
-                if (ti == PUB0 || ti == pub1) publish_bests(ql_t, sub_t, lists_t);
+                if (ti >= LANDT && polled_at(ti - LANDT)) poll_consume(ql_t);
+                if (ti == 0 || ti == pub1) publish_bests(ql_t, sub_t, lists_t);
                 if (wave == 0) {
-                    // responsible query j of a round: gathered at tile (round's publish) + 1 + j, reduced a tile later
-                    const int rel = ti >= pub1 + 1 ? ti - (pub1 + 1) : ti - (PUB0 + 1);
-                    if (rel >= 1 && rel <= n_resp && bx + (rel - 1) * walkers < QS_QROWS)
-                        compute_thr(bx + (rel - 1) * walkers);
-                    if (rel >= 0 && rel < n_resp && bx + rel * walkers < QS_QROWS) gather_issue(bx + rel * walkers);
+                    // responsible query j of a round: fetched at tile (round's publication) + 1 + j STEP, reduced LANDT
+                    // tiles later (STEP = LANDT: the reduction of query j and the fetch of query j + 1 share a tile end,
+                    // reduction first)
+                    const int rel = ti > pub1 ? ti - (pub1 + 1) : ti - 1;
+                    const int jc = rel - LANDT, jg = rel;
+                    if (jc >= 0 && jc % STEP == 0 && jc / STEP < n_resp && bx + (jc / STEP) * walkers < QS_QROWS)
+                        compute_thr(bx + (jc / STEP) * walkers);
+                    if (jg >= 0 && jg % STEP == 0 && jg / STEP < n_resp && bx + (jg / STEP) * walkers < QS_QROWS)
+                        gather_issue(bx + (jg / STEP) * walkers);
                     if (polled_at(ti)) poll_issue();
                 }
             }
@@ -659,15 +694,17 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// The product dispatches the 16x16x32 shape at list depth 5 (3.7 % ahead of 32x32x16 on the bare
+// walk in steady state, and hipcc keeps its tile loop free of spills; with the f32x16 accumulator tuples of the 32x32
+// shape it does not).  MMRAG_QSW_DEV builds (tools/ab_search.py) instantiate both shapes for 768-d fp16 only.
 bool qsw_supported(int dtype, unsigned row_bytes, int K, int mfma) {
     if (dtype != MMRAG_F16 && dtype != MMRAG_BF16) return false;
-    if (!(K == 5 || (K == 10 && mfma == 32))) return false;   // four lists per query at K = 10 leave no LDS to the ring
-    if (mfma != 16 && mfma != 32) return false;
+    if (K != 5) return false;   // four lists per query at K = 10 leave no LDS to the ring: search_qs.hip keeps that depth
     const unsigned nk = row_bytes / SLAB;
 #if defined(MMRAG_QSW_DEV)
-    return row_bytes % SLAB == 0 && nk == 12 && dtype == MMRAG_F16 && K == 5;
+    return (mfma == 16 || mfma == 32) && row_bytes % SLAB == 0 && nk == 12 && dtype == MMRAG_F16;
 #else
-    return row_bytes % SLAB == 0 && (nk == 6 || nk == 8 || nk == 12);
+    return mfma == 16 && row_bytes % SLAB == 0 && (nk == 6 || nk == 8 || nk == 12);
 #endif
 }
 
@@ -700,21 +737,13 @@ int qsw_launch(int dtype, int K, int mfma, const KParams &p, int grid_x, int gri
     kp.walkers = grid_x;
     kp.share_l2 = grid_y > 1;
     const int grid = grid_x * grid_y;
-    if (dtype == MMRAG_F16) {
-        if (K == 5 && mfma == 16) return qsw_launch_nk<MMRAG_F16, 5, 16>(kp, grid, s);
-        if (K == 5) return qsw_launch_nk<MMRAG_F16, 5, 32>(kp, grid, s);
-#if !defined(MMRAG_QSW_DEV)
-        if (K == 10) return qsw_launch_nk<MMRAG_F16, 10, 32>(kp, grid, s);
+#if defined(MMRAG_QSW_DEV)
+    if (mfma == 32) return qsw_launch_nk<MMRAG_F16, 5, 32>(kp, grid, s);
+    return qsw_launch_nk<MMRAG_F16, 5, 16>(kp, grid, s);
+#else
+    if (dtype == MMRAG_F16) return qsw_launch_nk<MMRAG_F16, 5, 16>(kp, grid, s);
+    return qsw_launch_nk<MMRAG_BF16, 5, 16>(kp, grid, s);
 #endif
-    }
-#if !defined(MMRAG_QSW_DEV)
-    else if (dtype == MMRAG_BF16) {
-        if (K == 5 && mfma == 16) return qsw_launch_nk<MMRAG_BF16, 5, 16>(kp, grid, s);
-        if (K == 5) return qsw_launch_nk<MMRAG_BF16, 5, 32>(kp, grid, s);
-        if (K == 10) return qsw_launch_nk<MMRAG_BF16, 10, 32>(kp, grid, s);
-    }
-#endif
-    return MMRAG_EUNSUPPORTED;
 }
 
 }  // namespace mmrag_impl

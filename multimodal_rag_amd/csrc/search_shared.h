@@ -55,6 +55,21 @@ struct TopList {
             xr = nxr;
         }
     }
+    // the same result with every compare against the OLD list (the list is sorted, so "x > v[j]" is false ... false
+    // true ... true): slot j keeps its entry, takes x, or takes its upper neighbour's.  Three dependent steps instead
+    // of 2 K: for a wave alone on its SIMD the dependent chain, not the instruction count, is what an insertion costs.
+    __device__ inline void insert_strict_flat(float x, int xr) {
+        bool c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = x > v[j];
+#pragma unroll
+        for (int j = K - 1; j >= 1; --j) {
+            v[j] = c[j] ? (c[j - 1] ? v[j - 1] : x) : v[j];
+            r[j] = c[j] ? (c[j - 1] ? r[j - 1] : xr) : r[j];
+        }
+        v[0] = c[0] ? x : v[0];
+        r[0] = c[0] ? xr : r[0];
+    }
 };
 
 struct KParams {
@@ -82,7 +97,6 @@ struct KParams {
                           // null = no in-kernel threshold seeding
     float *pub_thr;       // [query groups][256]: K-th largest of a query's published bests, -inf until computed
     unsigned *tickets;    // [query groups]: next dynamically handed-out tile, counted from TICKET0
-    int pub0;             // tile after which a workgroup first publishes its bests (0 = after its first tile)
     int p_static;         // tile positions every workgroup walks by the static rule (tile = bx + pos * walkers); the
                           // tiles from p_static * walkers on are handed out by ticket.  Huge = no dynamic hand-out
 };

@@ -304,6 +304,56 @@ def test_query_stationary_masks_offsets_ragged(N):
         check(*run(N, q, c, 5, torch.float16, alive=none, dbg=dbg))
 
 
+# ---- single-launch walk kernel (csrc/search_qsw.hip): list depth 5 on shards long enough for its in-kernel threshold
+# exchange (>= 12 tiles of 64 rows per workgroup) and its ticketed tail (>= 24, one query group).  Every case: the
+# default plan against the oracle, and bit for bit against the same kernel without tickets / without the exchange, the
+# three-launch kernel of search_qs.hip and the slab-ring kernel.
+@pytest.mark.parametrize("B,n,d,dtype", [
+    (256, 400_003, 768, torch.float16),     # exchange + tickets, ragged last tile
+    (300, 250_000, 768, torch.bfloat16),    # two query groups (128 walkers each): exchange, static tiles
+    (1000, 200_000, 384, torch.float16),    # four groups of 64 walkers: four thresholds per workgroup; 768-byte rows
+    (256, 420_000, 512, torch.float16),     # 1024-byte rows
+    (130, 393_300, 768, torch.float16),     # a half-empty query group
+])
+def test_walk_kernel_parity(N, B, n, d, dtype):
+    q = unit_rows(B, d, 71)
+    c = unit_rows(n, d, 72)
+    s, r, es, er = run(N, q, c, 5, dtype, dbg=N.DBG_FORCE_QS)
+    check(s, r, es, er)
+    qd, _ = to_dev(N, q, dtype)
+    cd, _ = to_dev(N, c, dtype)
+    for dbg in (N.DBG_FORCE_QS | N.DBG_NO_DYN, N.DBG_FORCE_QS | N.DBG_NO_SEED, N.DBG_FORCE_QS | N.DBG_NO_DYN | N.DBG_NO_SEED,
+                N.DBG_FORCE_QS | N.DBG_OLD_QS, N.DBG_NO_QS, 0):
+        s2, r2 = N.cosine_topk(qd, cd, n, d, 5, dbg=dbg)
+        assert np.array_equal(r2.cpu().numpy(), r) and np.array_equal(s2.cpu().numpy(), s), hex(dbg)
+    # the same workspace again: the exchange block of the last launch must not leak into this one
+    ws = torch.empty(N.cosine_topk_workspace_bytes(B, n, 5), dtype=torch.uint8, device="cuda")
+    q2d, _ = to_dev(N, unit_rows(B, d, 73), dtype)
+    a = N.cosine_topk(q2d, cd, n, d, 5, workspace=ws)
+    b = N.cosine_topk(qd, cd, n, d, 5, workspace=ws)
+    assert np.array_equal(b[1].cpu().numpy(), r) and np.array_equal(b[0].cpu().numpy(), s)
+    assert not np.array_equal(a[1].cpu().numpy(), r)
+
+
+def test_walk_kernel_masks_offsets_and_exact_ties(N):
+    """alive bitmask + shard row offset through the exchange and the ticketed tail; integer data (exact in fp16, ties
+    everywhere -> lower row) bit for bit against the oracle; k < 5 takes the same lists"""
+    n, d, B = 400_003, 768, 200
+    q = unit_rows(B, d, 81)
+    c = unit_rows(n, d, 82)
+    g = np.random.default_rng(83)
+    alive = g.random(n) < 0.5
+    check(*run(N, q, c, 5, torch.float16, row_offset=3_000_000, alive=alive, dbg=N.DBG_FORCE_QS))
+    few = np.zeros(n, dtype=bool)
+    few[[7, 200_000, n - 1]] = True            # 3 live rows < k: the exchange never yields a threshold
+    check(*run(N, q, c, 5, torch.float16, alive=few, dbg=N.DBG_FORCE_QS))
+    ci = g.integers(-2, 3, size=(n, 384)).astype(np.float32)
+    qi = g.integers(-2, 3, size=(256, 384)).astype(np.float32)
+    for k in (1, 3, 5):
+        s, r, es, er = run(N, qi, ci, k, torch.float16, dbg=N.DBG_FORCE_QS)
+        assert np.array_equal(s, es) and np.array_equal(r, er)
+
+
 # ---- fp32 storage, more than 64 queries: scores come from a 3-term bf16 split (csrc/search.hip); the bound is the
 # north star's 1e-4, tested on the reference's own vectors and on random data; integer data stays bit-exact
 def test_fp32_split_on_the_wal70_vectors(N, wal70):

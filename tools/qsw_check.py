@@ -29,7 +29,12 @@ for (n, B, integer) in [(400_000, 256, False), (400_000, 200, True), (399_937, 2
         if integer:
             good = torch.equal(r_, rr) and torch.equal(s_, rs)
         else:
-            good = torch.equal(r_, rr) and (s_ - rs).abs().max().item() < 2e-5
+            # ids may differ from the torch reference only between rows whose scores tie to rounding (different
+            # accumulation orders): the reference's score of every returned row must match the reference's list
+            full = (q.float() @ c[:n].float().T)
+            got_ref_scores = torch.gather(full, 1, r_)
+            good = (got_ref_scores - rs).abs().max().item() < 2e-6 and (s_ - rs).abs().max().item() < 2e-5 \
+                and all(len(set(x)) == k for x in r_.tolist())
         ok &= good
         print(f"n={n} B={B} int={integer} {name:18s} {'OK' if good else 'MISMATCH'}  rows_equal={torch.equal(r_, rr)} max|ds|={(s_-rs).abs().max().item():.2e}", flush=True)
         if not good:
