@@ -29,7 +29,10 @@ def synthetic_ids(n_chunks: int, seq: int, vocab: int, seed: int):
     return ids
 
 
-def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_baseline: bool = True):
+def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_baseline: bool = True,
+        extras: bool = True):
+    """`extras=False`: the headline shape only (tools/embed_once.py under rocprofv3: the kernel statistics of that run
+    must be the per-layer table of the bge S=256 step and nothing else)."""
     import torch.distributed as dist
 
     cfg = PRESETS["BAAI/bge-base-en-v1.5"]
@@ -109,6 +112,8 @@ def run(dev, rank: int, world: int, steps: int = 10, warmup: int = 2, with_cpu_b
             res["cpu_baseline"]["torch_cpu_error"] = str(e)[:200]
         res["parity_vs_oracle"] = bool(np.abs(got - ref).max() <= 4e-3 and (got * ref).sum(1).min() >= 0.9999)
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+    if not extras:
+        return res
     try:   # "bge 512 and 256", MiniLM (configs 1-2) 256, and ragged lengths
         res["other_shapes"] = bench_other_shapes(dev)
     except Exception as e:

@@ -26,7 +26,8 @@ def main(tag):
     for f, dst in (("bench.json", f"{tag}_bench.json"),):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(out, dst))
-    for sub, dst in (("stats", f"{tag}_kernel_stats.csv"), ("embed_stats", f"{tag}_embed_kernel_stats.csv")):
+    for sub, dst in (("stats", f"{tag}_kernel_stats.csv"), ("embed_stats", f"{tag}_embed_kernel_stats.csv"),
+                     ("embed_other_stats", f"{tag}_embed_other_shapes_kernel_stats.csv")):
         f = find(tag, sub, "*kernel_stats.csv")
         if f:
             rows = [r for r in csv.reader(open(f))]
@@ -40,19 +41,22 @@ def main(tag):
         f = find(tag, sub, "*counter_collection.csv")
         if not f:
             return None, 0
-        tot, scans, merges = 0.0, 0, 0
+        tot, walks, seeds = 0.0, 0, 0
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter or not ours(r["Kernel_Name"]):
                 continue
             if "cosine_topk" in r["Kernel_Name"] or "qs_seed" in r["Kernel_Name"]:
                 tot += float(r["Counter_Value"])
-            scans += "qs_seed_thr_kernel" in r["Kernel_Name"]
+            walks += "cosine_topk_walk_kernel" in r["Kernel_Name"]      # single-launch plan: one per scan
+            seeds += "qs_seed_thr_kernel" in r["Kernel_Name"]           # three-launch plan: one per scan
+        scans = walks or seeds
         return (tot / scans if scans else None), scans
 
     fetch, n1 = per_scan("pmc_fetch", "FETCH_SIZE")
     write, n2 = per_scan("pmc_write", "WRITE_SIZE")
     if fetch is not None:
-        t = {"kernel": "cosine_topk_qs_kernel (sample pass + walk) + qs_seed_thr_kernel", "rows_per_gpu": 1000000,
+        t = {"kernel": "the search kernels of one scan (cosine_topk_walk_kernel; before round 3: sample pass + "
+                       "qs_seed_thr_kernel + walk)", "rows_per_gpu": 1000000,
              "batch": 256, "scans": n1, "fetch_size_kib_raw": fetch, "hbm_read_bytes_per_launch": fetch * 1024 * 2,
              "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 counts 128-B requests at 64 B)",
              "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, round {tag}"}
@@ -87,4 +91,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")

@@ -2,7 +2,7 @@
 # Evidence pass on the GPU box (run through gpurun): bench line, rocprofv3 kernel stats and PMC passes of the retrieve
 # leg and of the embed leg.  Outputs under gpurun_out/<tag>/; tools/collect_profiles.py turns them into profiles/<tag>_*.
 # usage: tools/profile_round.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -20,4 +20,5 @@ prof pmc_write --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o c -- 
 prof pmc_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o c -- $BENCH --steps 10 --warmup 2
 prof embed_stats --kernel-trace --stats --output-format csv -d "$OUT/embed_stats" -o s -- python3 tools/embed_once.py
 prof embed_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/embed_mfma" -o c -- python3 tools/embed_once.py
+prof embed_other_stats --kernel-trace --stats --output-format csv -d "$OUT/embed_other_stats" -o s -- python3 tools/embed_other_once.py
 ls "$OUT"
