@@ -197,6 +197,18 @@ void mmrag_wordpiece_destroy(void *tokenizer);
 int mmrag_wordpiece_encode_batch(const void *tokenizer, const uint32_t *cps, const int64_t *offsets, int n,
                                  int max_length, int32_t *ids, int32_t *lens, int n_threads);
 
+/* CLIP byte-level BPE (the text tower's tokenizer, BASELINE config 4; the reference only names CLIP in config.py:106).
+ * Host code, multi-threaded; equals multimodal_rag_amd/tokenizer.py:ClipBpeTokenizer, which tests pin to
+ * transformers.CLIPTokenizer.  The caller passes text already NFC-normalised, whitespace-collapsed and lower-cased.
+ *   mmrag_clip_bpe_create   vocabulary entries as UTF-32 strings with their ids, merges ("first second") in rank order;
+ *                           NULL (see mmrag_last_error) without <|startoftext|> / <|endoftext|>
+ *   mmrag_clip_bpe_encode_batch  ids [n, max_length] int32, rows [sot] ids[: max_length - 2] [eot]; lens [n] */
+void *mmrag_clip_bpe_create(const uint32_t *vocab_cps, const int64_t *vocab_offsets, const int32_t *vocab_ids,
+                            int n_vocab, const uint32_t *merge_cps, const int64_t *merge_offsets, int n_merges);
+void mmrag_clip_bpe_destroy(void *tokenizer);
+int mmrag_clip_bpe_encode_batch(const void *tokenizer, const uint32_t *cps, const int64_t *offsets, int n,
+                                int max_length, int32_t *ids, int32_t *lens, int n_threads);
+
 /* Image front end of the vision tower (BASELINE config 4; the reference has no image encoder):
  * CLIP's preprocessing = shortest edge -> 224 with PIL bicubic, centre crop, done on uint8.  Bit-exact with
  * Pillow's 8-bit resampler (two integer passes, 22-bit fixed-point taps).

@@ -91,6 +91,12 @@ def _declare(lib):
     lib.mmrag_wordpiece_destroy.argtypes = [c_void_p]
     lib.mmrag_wordpiece_encode_batch.restype = c_int
     lib.mmrag_wordpiece_encode_batch.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]
+    lib.mmrag_clip_bpe_create.restype = c_void_p
+    lib.mmrag_clip_bpe_create.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]
+    lib.mmrag_clip_bpe_destroy.restype = None
+    lib.mmrag_clip_bpe_destroy.argtypes = [c_void_p]
+    lib.mmrag_clip_bpe_encode_batch.restype = c_int
+    lib.mmrag_clip_bpe_encode_batch.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]
     lib.mmrag_resample_ksize.restype = c_int
     lib.mmrag_resample_ksize.argtypes = [c_int, c_int]
     lib.mmrag_resample_coeffs.restype = c_int

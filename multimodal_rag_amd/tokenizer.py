@@ -302,3 +302,67 @@ class ClipBpeTokenizer:
             else:
                 ids.extend(self._bpe(tok))
         return [self.sot] + ids[: max(0, max_length - 2)] + [self.eot]
+
+
+class NativeClipBpeTokenizer:
+    """The same tokenisation as `ClipBpeTokenizer`, done by libmmrag.so's multi-threaded C++ routine
+    (csrc/clip_bpe.cpp): NFC, whitespace collapse and lower-casing stay here (C-speed str methods), the pattern
+    split, byte mapping, merges and lookup are native.  Host-only: works without a GPU."""
+
+    def __init__(self, vocab: Dict[str, int], merges: List[str], context_length: int = 77, n_threads: int = 0):
+        import os
+
+        import numpy as np
+        import regex
+
+        from . import _native
+
+        self._lib = _native.lib()
+        toks = list(vocab.keys())
+        v_cps, v_offs = _utf32(toks)
+        v_ids = np.asarray([vocab[t] for t in toks], dtype=np.int32)
+        good = [ln for ln in merges if len(ln.split()) == 2]
+        m_cps, m_offs = _utf32([" ".join(ln.split()) for ln in good])
+        self._h = self._lib.mmrag_clip_bpe_create(v_cps.ctypes.data, v_offs.ctypes.data, v_ids.ctypes.data, len(toks),
+                                                  m_cps.ctypes.data, m_offs.ctypes.data, len(good))
+        if not self._h:
+            raise RuntimeError(self._lib.mmrag_last_error().decode())
+        self.sot, self.eot = vocab["<|startoftext|>"], vocab["<|endoftext|>"]
+        self.context_length = context_length
+        self.n_threads = n_threads or min(32, os.cpu_count() or 1)
+        self._ws = regex.compile(r"\s+")
+        self._np = np
+
+    @classmethod
+    def from_files(cls, vocab_json: str, merges_txt: str, context_length: int = 77, n_threads: int = 0):
+        py = ClipBpeTokenizer.from_files(vocab_json, merges_txt, context_length)
+        with open(merges_txt, encoding="utf-8") as f:
+            lines = [ln.rstrip("\n") for ln in f]
+        if lines and lines[0].startswith("#"):
+            lines = lines[1:]
+        return cls(py.vocab, [ln for ln in lines if ln.strip()], context_length, n_threads)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mmrag_clip_bpe_destroy(h)
+
+    def encode_batch_arrays(self, texts: List[str], max_length: int = 0):
+        """(ids [n, max_length] int32, lens [n] int32): rows are [sot] ... [eot]; entries past lens[i] are unspecified."""
+        np = self._np
+        max_length = max_length or self.context_length
+        cps, offs = _utf32([self._ws.sub(" ", unicodedata.normalize("NFC", t)).lower() for t in texts])
+        ids = np.empty((len(texts), max_length), np.int32)
+        lens = np.empty(len(texts), np.int32)
+        st = self._lib.mmrag_clip_bpe_encode_batch(self._h, cps.ctypes.data, offs.ctypes.data, len(texts), max_length,
+                                                   ids.ctypes.data, lens.ctypes.data, self.n_threads)
+        if st:
+            raise RuntimeError(self._lib.mmrag_last_error().decode())
+        return ids, lens
+
+    def encode_batch(self, texts: List[str], max_length: int = 0) -> List[List[int]]:
+        ids, lens = self.encode_batch_arrays(texts, max_length)
+        return [ids[i, : lens[i]].tolist() for i in range(len(texts))]
+
+    def encode(self, text: str, max_length: int = 0) -> List[int]:
+        return self.encode_batch([text], max_length)[0]

@@ -139,12 +139,59 @@ static void merge_checks() {
     CHECK(mmrag_merge_topk_host(nullptr, nullptr, 1, 1, 1, 1, &o, &orow) != MMRAG_OK);
 }
 
+static void clip_bpe_checks() {
+    // byte-level BPE: a handful of merges over ASCII (the printable table maps ASCII letters to themselves)
+    std::vector<std::string> vocab = {"a", "b", "c", "a</w>", "b</w>", "c</w>", "ab", "ab</w>", "abc</w>", "'s</w>", "!</w>",
+                                      "<|startoftext|>", "<|endoftext|>"};
+    std::vector<std::string> merges = {"a b", "a b</w>", "ab c</w>", "' s</w>"};
+    auto pack = [](const std::vector<std::string> &v, std::vector<uint32_t> &cps, std::vector<int64_t> &off) {
+        off.assign(1, 0);
+        for (auto &t : v) {
+            auto c = cps_of(t);
+            cps.insert(cps.end(), c.begin(), c.end());
+            off.push_back((int64_t)cps.size());
+        }
+    };
+    std::vector<uint32_t> vc, mc;
+    std::vector<int64_t> vo, mo;
+    pack(vocab, vc, vo);
+    pack(merges, mc, mo);
+    std::vector<int32_t> ids(vocab.size());
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = (int32_t)i;
+    void *tk = mmrag_clip_bpe_create(vc.data(), vo.data(), ids.data(), (int)vocab.size(), mc.data(), mo.data(), (int)merges.size());
+    CHECK(tk != nullptr);
+    std::vector<std::string> words = {"abc", "ab", "a's", "cab!", "", "  ", "<|endoftext|>", "abcabcabc", "zzz", "a b c"};
+    std::mt19937 rng(9);
+    const int n = 3000, L = 24;
+    std::vector<uint32_t> text;
+    std::vector<int64_t> toff = {0};
+    for (int i = 0; i < n; ++i) {
+        std::string s;
+        for (int k = (int)(rng() % 8); k > 0; --k) s += words[rng() % words.size()] + (rng() % 3 ? " " : "");
+        auto c = cps_of(s);
+        text.insert(text.end(), c.begin(), c.end());
+        toff.push_back((int64_t)text.size());
+    }
+    std::vector<int32_t> ids1((size_t)n * L), ids8((size_t)n * L), len1(n), len8(n);
+    CHECK(mmrag_clip_bpe_encode_batch(tk, text.data(), toff.data(), n, L, ids1.data(), len1.data(), 1) == MMRAG_OK);
+    CHECK(mmrag_clip_bpe_encode_batch(tk, text.data(), toff.data(), n, L, ids8.data(), len8.data(), 8) == MMRAG_OK);
+    for (int i = 0; i < n; ++i) {
+        CHECK(len1[i] == len8[i] && len1[i] >= 2 && len1[i] <= L);
+        CHECK(ids1[(size_t)i * L] == 11 && ids1[(size_t)i * L + len1[i] - 1] == 12);
+        for (int j = 0; j < len1[i]; ++j) CHECK(ids1[(size_t)i * L + j] == ids8[(size_t)i * L + j]);
+    }
+    CHECK(mmrag_clip_bpe_encode_batch(tk, text.data(), toff.data(), n, 1, ids1.data(), len1.data(), 1) != MMRAG_OK);
+    mmrag_clip_bpe_destroy(tk);
+    CHECK(mmrag_clip_bpe_create(vc.data(), vo.data(), ids.data(), 3, mc.data(), mo.data(), 0) == nullptr);   // no specials
+}
+
 int main() {
     tokenizer_checks();
+    clip_bpe_checks();
     merge_checks();
     // concurrent merges + tokenisation (no shared mutable state is the claim)
     std::vector<std::thread> th;
-    for (int i = 0; i < 4; ++i) th.emplace_back(i % 2 ? merge_checks : tokenizer_checks);
+    for (int i = 0; i < 6; ++i) th.emplace_back(i % 3 == 0 ? merge_checks : (i % 3 == 1 ? tokenizer_checks : clip_bpe_checks));
     for (auto &t : th) t.join();
     printf("sanitize_host: ok\n");
     return 0;

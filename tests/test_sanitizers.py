@@ -1,4 +1,4 @@
-"""CPU only: the host-side C++ of libmmrag.so (multi-threaded tokenizer, host merge) under AddressSanitizer +
+"""CPU only: the host-side C++ of libmmrag.so (multi-threaded tokenizers, host merge) under AddressSanitizer +
 UndefinedBehaviorSanitizer and under ThreadSanitizer.  Never run on the GPU box."""
 import os
 import shutil
@@ -26,7 +26,8 @@ def test_host_cpp_under_sanitizers(tmp_path, name, flags):
     exe = str(tmp_path / f"sanitize_host_{name}")
     # host-only compile of the two translation units (they include the HIP headers through mmrag_internal.h)
     cmd = [hipcc, "-x", "hip", "--cuda-host-only", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", *flags,
-           "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "tokenizer.cpp"), os.path.join(CSRC, "host_merge.cpp"),
+           "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "tokenizer.cpp"), os.path.join(CSRC, "clip_bpe.cpp"),
+           os.path.join(CSRC, "host_merge.cpp"),
            DRIVER, "-o", exe, "-lpthread"]
     build = subprocess.run(cmd, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]

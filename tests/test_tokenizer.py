@@ -80,6 +80,63 @@ def test_clip_bpe_shape_rules():
     assert tk.eot == max(tk.vocab.values())  # EOS pooling picks argmax(id): the end token must be the largest id
 
 
+# ---- native (C++) CLIP BPE (csrc/clip_bpe.cpp): must equal the Python form above, which is pinned to transformers -----
+def _native_clip_tok(n_threads=3):
+    from multimodal_rag_amd.tokenizer import NativeClipBpeTokenizer
+
+    return NativeClipBpeTokenizer.from_files(os.path.join(GOLD, "clip_bpe_vocab.json"),
+                                             os.path.join(GOLD, "clip_bpe_merges.txt"), n_threads=n_threads)
+
+
+def test_native_clip_bpe_matches_committed_golden():
+    exp = json.load(open(os.path.join(GOLD, "clip_bpe_expected.json"), encoding="utf-8"))
+    nat = _native_clip_tok()
+    assert (nat.sot, nat.eot) == (exp["sot"], exp["eot"])
+    texts = [c["text"] for c in exp["cases"]]
+    assert nat.encode_batch(texts) == [c["ids"] for c in exp["cases"]]
+    assert nat.encode_batch(texts, 16) == [c["ids_16"] for c in exp["cases"]]
+    ids, lens = nat.encode_batch_arrays(["retrieval " * 200, ""])
+    assert ids.shape == (2, 77) and lens.tolist() == [77, 2] and ids[0, 0] == nat.sot and ids[0, 76] == nat.eot
+
+
+def test_native_clip_bpe_fuzz_against_python():
+    """pattern corner cases: contractions next to punctuation, the special tokens inside text, digits one by one,
+    letters / numbers / marks of many scripts, every whitespace class, emoji and astral planes, NFC recomposition"""
+    import random
+
+    py, nat = _clip_tok(), _native_clip_tok()
+    pieces = ["don't", "you'll", "we've", "i'm", "he'd", "it's", "'re", "'", "''s", "!'s", "x'sx", "<|startoftext|>",
+              "<|endoftext|>", "<|endoftext", "<|", "|>", "a1b22c333", "12345", "٣٤", "Ⅻ", "½",
+              "naïve", "naïve", "Å", "가", "straße", "İstanbul", "ΑΣ",
+              "日本語", "テスト", "한국어", "क्षि", "\U0001f600",
+              "\U0001f642\U0001f642", "\U0001d518\U0001d52b\U0001d526", " ", " ", "　", "\t", "\n", "\r\n", "\x0b",
+              "\x1c", "​", "﻿", "--", "...", "(a)", "[b]", "{c}", "#$%", "retrieval", "throughput", "figure",
+              "Figure 3:", "batch-size", "GPU", "mi355x", "the", "quick", "brown"]
+    rng = random.Random(5)
+    texts = []
+    for _ in range(3000):
+        k = rng.randint(0, 9)
+        parts = [rng.choice(pieces) for _ in range(k)]
+        texts.append(rng.choice(["", " ", "  "]).join(parts) if rng.random() < 0.5 else " ".join(parts))
+    texts += ["".join(chr(rng.choice([rng.randint(32, 126), rng.randint(0xA0, 0x24F), rng.randint(0x370, 0x3FF),
+                                       rng.randint(0x4E00, 0x4E80), rng.randint(0x1F600, 0x1F64F), 32]))
+                      for _ in range(rng.randint(0, 60))) for _ in range(1500)]
+    for max_len in (77, 9):
+        want = [py.encode(t, max_len) for t in texts]
+        got = nat.encode_batch(texts, max_len)
+        bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+        assert not bad, (texts[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_clip_tables_are_current():
+    """csrc/clip_bpe_tables.inc was generated from the regex module installed here"""
+    import regex
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = open(os.path.join(root, "multimodal_rag_amd", "csrc", "clip_bpe_tables.inc")).readline()
+    assert f"regex {regex.__version__}" in head, "re-run tools/gen_clip_tables.py"
+
+
 # ---- native (C++) WordPiece: must equal the Python restatement, which is pinned to transformers above ---------
 def _native_pair(extra=()):
     from multimodal_rag_amd.tokenizer import NativeWordPieceTokenizer
