@@ -155,18 +155,25 @@ def bench_other_shapes(dev):
     """Forward-only chunks/s at the other shapes SURVEY 8d names: bge-base S=512, all-MiniLM-L6-v2 S=256, and
     bge-base with clipped log-normal lengths (mean ~180, max 256; no padded tokens are computed)."""
     res = {}
-    for name, key, S, chunks in (("bge_base_s512", "BAAI/bge-base-en-v1.5", 512, 128),
-                                 ("minilm_l6_s256", "sentence-transformers/all-MiniLM-L6-v2", 256, 256)):
+    F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: the float32 matrix rate (MI355X_MICROARCH.md)
+    for name, key, S, chunks, precision in (
+            ("bge_base_s512", "BAAI/bge-base-en-v1.5", 512, 128, "fp16"),
+            ("minilm_l6_s256", "sentence-transformers/all-MiniLM-L6-v2", 256, 256, "fp16"),
+            # the reference's own precision (SentenceTransformer.encode is float32): csrc/encoder_f32.hip
+            ("minilm_l6_s256_fp32", "sentence-transformers/all-MiniLM-L6-v2", 256, 256, "fp32"),
+            ("bge_base_s256_fp32", "BAAI/bge-base-en-v1.5", 256, 64, "fp32")):
         cfg = PRESETS[key]
-        enc = DeviceEncoder(cfg, random_bert_weights(cfg, seed=77, device=dev), dev)
+        enc = DeviceEncoder(cfg, random_bert_weights(cfg, seed=77, device=dev), dev, precision=precision)
         ids = torch.from_numpy(synthetic_ids(chunks, S, cfg.vocab, seed=9).reshape(-1)).to(dev)
         pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(chunks)
         cu = torch.arange(0, (chunks + 1) * S, S, dtype=torch.int32, device=dev)
         out = torch.empty((chunks, cfg.dim), dtype=torch.float32, device=dev)
         ms = _time_forward(enc, ids, pos, cu, S, out)
         tf = chunks * enc.flops_per_sequence(S) / (ms * 1e-3) / 1e12
+        peak = MFMA_F16_PEAK_TFLOPS if precision == "fp16" else F32_MFMA_PEAK_TFLOPS
         res[name] = {"chunks_per_s": round(chunks / ms * 1e3, 1), "ms_per_step": round(ms, 3), "chunks_per_step": chunks,
-                     "seq_len": S, "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4)}
+                     "seq_len": S, "dtype": "f16" if precision == "fp16" else "f32", "tflops": round(tf, 1),
+                     "mfma_peak_tflops": peak, "mfma_frac": round(tf / peak, 4)}
         del enc
     cfg = PRESETS["BAAI/bge-base-en-v1.5"]
     enc = DeviceEncoder(cfg, random_bert_weights(cfg, seed=78, device=dev), dev)

@@ -170,6 +170,20 @@ int mmrag_encoder_forward(const mmrag_encoder_desc *desc, const void *const *w, 
                           int64_t T, int B, int max_len, float *out, void *workspace,
                           size_t workspace_bytes, void *stream);
 
+/* The encoder at the reference's own precision (opt-in; MMRAG_ENCODER_PRECISION=fp32).  SentenceTransformer.encode runs
+ * in float32 (app/utils/embedder.py:397-403, device pick :204-210, no autocast anywhere); this entry point computes as
+ * it does: float32 weights and activations, every contraction on the exact float32 matrix instruction
+ * (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain), LayerNorm / softmax / erf-GELU / pooling in float32.  BERT family
+ * only.  Same arguments as mmrag_encoder_forward; the weight table has the same order with EVERY entry float32
+ * (matrices [out_features][in_features]).  Throughput is bound by the float32 matrix rate (1/16 of fp16).
+ *   mmrag_linear_f32   the GEMM of that mode on its own (parity tests): out = act(x . wt^T + bias) (+ resid) */
+size_t mmrag_encoder_f32_workspace_bytes(const mmrag_encoder_desc *desc, int64_t T, int B);
+int mmrag_encoder_forward_f32(const mmrag_encoder_desc *desc, const void *const *w, const int32_t *ids,
+                              const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel, int64_t T, int B,
+                              int max_len, float *out, void *workspace, size_t workspace_bytes, void *stream);
+int mmrag_linear_f32(const float *x, int64_t M, int K, const float *wt, int N, const float *bias, int act,
+                     const float *resid, float *out, void *stream);
+
 /* Vision tower (CLIP ViT-B/32 shape; BASELINE config 4 -- no reference behaviour):
  * patchify (+ fused uint8 -> normalised fp16 preprocessing) -> patch-embedding GEMM -> class token +
  * positions -> pre-LN -> the same pre-LN blocks / final LN / projection / L2 normalise as the text tower.

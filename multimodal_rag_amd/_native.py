@@ -82,6 +82,12 @@ def _declare(lib):
     lib.mmrag_encoder_forward.restype = c_int
     lib.mmrag_encoder_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.mmrag_encoder_f32_workspace_bytes.restype = c_size_t
+    lib.mmrag_encoder_f32_workspace_bytes.argtypes = [c_void_p, c_int64, c_int]
+    lib.mmrag_encoder_forward_f32.restype = c_int
+    lib.mmrag_encoder_forward_f32.argtypes = lib.mmrag_encoder_forward.argtypes
+    lib.mmrag_linear_f32.restype = c_int
+    lib.mmrag_linear_f32.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     lib.mmrag_vit_forward.restype = c_int
     lib.mmrag_vit_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                       c_void_p]
@@ -473,24 +479,43 @@ def pool_normalize_f16(x: torch.Tensor, cu_seqlens: torch.Tensor, pool: int, nor
     return out
 
 
-def encoder_workspace_bytes(desc: EncoderDesc, T: int, B: int) -> int:
+def encoder_workspace_bytes(desc: EncoderDesc, T: int, B: int, f32: bool = False) -> int:
+    if f32:
+        return int(lib().mmrag_encoder_f32_workspace_bytes(ctypes.byref(desc), T, B))
     return int(lib().mmrag_encoder_workspace_bytes(ctypes.byref(desc), T, B))
+
+
+def linear_f32(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+               resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(x . wt^T + bias) (+ resid), float32 on the exact float32 matrix instruction (the fp32 encoder's GEMM)"""
+    _dev_check(x, wt, bias, resid)
+    M, K = x.shape
+    N = wt.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib().mmrag_linear_f32(x.data_ptr(), M, K, wt.data_ptr(), N, _ptr(bias), act, _ptr(resid), out.data_ptr(),
+                                    _stream_ptr(x.device))
+    _check(st, "mmrag_linear_f32")
+    return out
 
 
 def encoder_forward(desc: EncoderDesc, weight_ptrs, ids: torch.Tensor, pos_ids: torch.Tensor,
                     cu_seqlens: torch.Tensor, max_len: int, sel: Optional[torch.Tensor] = None,
-                    workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                    f32: bool = False) -> torch.Tensor:
     """One encoder pass over packed token ids -> [B, out_dim] float32.  `weight_ptrs` is a ctypes
-    array of c_void_p in the order include/mmrag.h documents (see encoder.DeviceEncoder)."""
+    array of c_void_p in the order include/mmrag.h documents (see encoder.DeviceEncoder).  `f32`: the float32 mode
+    (mmrag_encoder_forward_f32; every weight float32)."""
     _dev_check(ids, pos_ids, cu_seqlens, sel, workspace, out)
     T, B = ids.numel(), cu_seqlens.numel() - 1
-    need = encoder_workspace_bytes(desc, T, B)
+    need = encoder_workspace_bytes(desc, T, B, f32)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=ids.device)
     if out is None:
         out = torch.empty((B, desc.out_dim), dtype=torch.float32, device=ids.device)
+    fn = lib().mmrag_encoder_forward_f32 if f32 else lib().mmrag_encoder_forward
     with torch.cuda.device(ids.device):
-        st = lib().mmrag_encoder_forward(ctypes.byref(desc), weight_ptrs, ids.data_ptr(), pos_ids.data_ptr(),
+        st = fn(ctypes.byref(desc), weight_ptrs, ids.data_ptr(), pos_ids.data_ptr(),
                                          cu_seqlens.data_ptr(), _ptr(sel), T, B, max_len, out.data_ptr(),
                                          workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                          _stream_ptr(ids.device))

@@ -20,7 +20,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmmrag.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
-SOURCES = ["common.hip", "search.hip", "search_qs.hip", "search_qsw.hip", "encoder.hip", "image.hip", "microbench.hip", "host_merge.cpp", "tokenizer.cpp", "clip_bpe.cpp"]
+SOURCES = ["common.hip", "search.hip", "search_qs.hip", "search_qsw.hip", "encoder.hip", "encoder_f32.hip", "image.hip", "microbench.hip", "host_merge.cpp", "tokenizer.cpp", "clip_bpe.cpp"]
 ARCH = "gfx950"
 
 

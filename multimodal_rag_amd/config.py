@@ -43,6 +43,9 @@ class Settings:
     MMRAG_MODEL_DIR: str = field(default_factory=lambda: os.getenv("MMRAG_MODEL_DIR", ""))
     MMRAG_INDEX_DTYPE: str = field(default_factory=lambda: os.getenv("MMRAG_INDEX_DTYPE", "float16"))
     MMRAG_WEIGHT_SEED: int = field(default_factory=lambda: int(os.getenv("MMRAG_WEIGHT_SEED", "0")))
+    # "fp16" (throughput path) or "fp32": the reference's own arithmetic (SentenceTransformer.encode is float32,
+    # embedder.py:397-403) -- scores within 1e-4 of the float32 model; pair it with MMRAG_INDEX_DTYPE=float32
+    MMRAG_ENCODER_PRECISION: str = field(default_factory=lambda: os.getenv("MMRAG_ENCODER_PRECISION", "fp16"))
     # keep the collection across restarts: load it from CHROMA_PERSIST_DIR/mmrag_index in initialize(), save it there in
     # cleanup().  Off by default, as in the reference's current code: its chromadb.Client(Settings(persist_directory=...))
     # lacks is_persistent=True, i.e. the reference's collection is in-memory too

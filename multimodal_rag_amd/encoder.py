@@ -94,15 +94,26 @@ def random_bert_weights(cfg: EncoderConfig, seed: int = 0, device="cuda:0", std:
 class DeviceEncoder:
     """BERT-family sentence encoder resident on one GPU."""
 
-    def __init__(self, cfg: EncoderConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device="cuda:0"):
+    def __init__(self, cfg: EncoderConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device="cuda:0",
+                 precision: str = "fp16"):
+        """`precision`: "fp16" (fp16 weights / activations, float32 accumulation and statistics: the throughput
+        path) or "fp32" (the reference's own arithmetic -- SentenceTransformer.encode runs in float32,
+        embedder.py:397-403: float32 weights and activations on the exact float32 matrix instruction; ~1/10 of the
+        fp16 path's throughput, embeddings within 2e-5 of the float32 model)."""
         _native.lib()
+        if precision not in ("fp16", "fp32"):
+            raise ValueError(f"precision must be 'fp16' or 'fp32', not {precision!r}")
         self.cfg = cfg
+        self.precision = precision
+        self._f32 = precision == "fp32"
         self.device = torch.device(device)
         self._tensors: List[torch.Tensor] = []   # keeps the HBM weight table alive
         ptrs: List[Optional[int]] = []
 
         def up(x, dtype):
             t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            if self._f32:
+                dtype = torch.float32
             t = t.to(device=self.device, dtype=dtype).contiguous()
             self._tensors.append(t)
             ptrs.append(t.data_ptr())
@@ -141,16 +152,18 @@ class DeviceEncoder:
         # ENQUEUED; stream order then keeps the forwards apart on the device.
         self._launch_lock = threading.Lock()
         self._graphs = {}                 # token count -> captured single-sequence forward (encode_one)
-        self._use_graphs = os.environ.get("MMRAG_ENCODER_GRAPHS", "1") not in ("0", "false", "no")
+        self._use_graphs = os.environ.get("MMRAG_ENCODER_GRAPHS", "1") not in ("0", "false", "no") and not self._f32
 
     # ---------------------------------------------------------------- constructors ---------
     @classmethod
-    def random_init(cls, cfg: EncoderConfig, seed: int = 0, device="cuda:0", std: float = 0.02) -> "DeviceEncoder":
+    def random_init(cls, cfg: EncoderConfig, seed: int = 0, device="cuda:0", std: float = 0.02,
+                    precision: str = "fp16") -> "DeviceEncoder":
         """Seeded random weights of the named architecture, generated on the device."""
-        return cls(cfg, random_bert_weights(cfg, seed, device, std), device)
+        return cls(cfg, random_bert_weights(cfg, seed, device, std), device, precision)
 
     @classmethod
-    def from_local_dir(cls, path: str, device="cuda:0", max_seq_length: Optional[int] = None) -> "DeviceEncoder":
+    def from_local_dir(cls, path: str, device="cuda:0", max_seq_length: Optional[int] = None,
+                       precision: str = "fp16") -> "DeviceEncoder":
         """Load a BERT-family checkpoint from a local Hugging Face style directory
         (config.json + model.safetensors).  Nothing is downloaded."""
         from safetensors.numpy import load_file
@@ -173,7 +186,7 @@ class DeviceEncoder:
                             c.get("layer_norm_eps", 1e-12))
         raw = load_file(os.path.join(path, "model.safetensors"))
         w = {(k[5:] if k.startswith("bert.") else k): v for k, v in raw.items()}
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, precision)
 
     # ---------------------------------------------------------------- forward ---------------
     def pack(self, sequences: Sequence[Sequence[int]]):
@@ -274,12 +287,12 @@ class DeviceEncoder:
     def forward_packed(self, ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         T, B = ids.numel(), cu_seqlens.numel() - 1
-        need = _native.encoder_workspace_bytes(self.desc, T, B)
+        need = _native.encoder_workspace_bytes(self.desc, T, B, self._f32)
         with self._launch_lock:
             if self._workspace is None or self._workspace.numel() < need:
                 self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
             return _native.encoder_forward(self.desc, self._ptrs, ids, pos_ids, cu_seqlens, max_len,
-                                           workspace=self._workspace, out=out)
+                                           workspace=self._workspace, out=out, f32=self._f32)
 
     @property
     def dim(self) -> int:

@@ -39,7 +39,7 @@ class HipEngine:
 
         model_dir = settings.MMRAG_MODEL_DIR
         if model_dir:
-            self.encoder = DeviceEncoder.from_local_dir(model_dir, self.device)
+            self.encoder = DeviceEncoder.from_local_dir(model_dir, self.device, precision=settings.MMRAG_ENCODER_PRECISION)
             vocab = os.path.join(model_dir, "vocab.txt")
             self.tokenizer = (NativeWordPieceTokenizer.from_vocab_file(vocab) if os.path.exists(vocab)
                               else HashTokenizer(self.encoder.cfg.vocab))
@@ -48,7 +48,8 @@ class HipEngine:
                 raise ValueError(f"unknown model {model_name!r}: give MMRAG_MODEL_DIR or one of {sorted(PRESETS)}")
             logger.warning("No local checkpoint (MMRAG_MODEL_DIR unset): %s architecture with seeded random "
                            "weights and the stand-in hash tokenizer", model_name)
-            self.encoder = DeviceEncoder.random_init(PRESETS[model_name], settings.MMRAG_WEIGHT_SEED, self.device)
+            self.encoder = DeviceEncoder.random_init(PRESETS[model_name], settings.MMRAG_WEIGHT_SEED, self.device,
+                                                     precision=settings.MMRAG_ENCODER_PRECISION)
             self.tokenizer = HashTokenizer(self.encoder.cfg.vocab)
         self.dim = self.encoder.dim
         self.max_seq_length = self.encoder.cfg.max_seq_length
