@@ -42,6 +42,11 @@ class Settings:
     # empty the named architecture is random-initialised and a stand-in tokenizer is used
     MMRAG_MODEL_DIR: str = field(default_factory=lambda: os.getenv("MMRAG_MODEL_DIR", ""))
     MMRAG_INDEX_DTYPE: str = field(default_factory=lambda: os.getenv("MMRAG_INDEX_DTYPE", "float16"))
+    # float32 collections: batches of more than 64 queries are scored on the bf16 matrix pipe from a three-term split
+    # of the float32 operands (|score error| <= 4e-5: approximate, and a query's score then depends on how many
+    # requests the dispatcher batched it with).  "true" keeps the exact float32 matrix instruction for every batch
+    # size (the batch is scanned 64 queries at a time: identical scores whatever the batch, ~2.5x the scan time)
+    MMRAG_F32_EXACT_SEARCH: bool = field(default_factory=lambda: _b("MMRAG_F32_EXACT_SEARCH", "false"))
     MMRAG_WEIGHT_SEED: int = field(default_factory=lambda: int(os.getenv("MMRAG_WEIGHT_SEED", "0")))
     # "fp16" (throughput path) or "fp32": the reference's own arithmetic (SentenceTransformer.encode is float32,
     # embedder.py:397-403) -- scores within 1e-4 of the float32 model; pair it with MMRAG_INDEX_DTYPE=float32

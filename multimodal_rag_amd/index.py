@@ -181,6 +181,9 @@ class VectorIndex:
         self._row_of: Dict[str, int] = {}
         self._lock = threading.RLock()
         self._search_ws: Optional[torch.Tensor] = None    # candidate-list workspace of the search kernels, reused
+        from .config import settings
+
+        self.f32_exact = bool(settings.MMRAG_F32_EXACT_SEARCH)   # float32 collections only (see config.py)
 
     @staticmethod
     def _n_words(rows: int) -> int:
@@ -351,6 +354,12 @@ class VectorIndex:
             raise ValueError("n_results must be >= 1")
         q = self._pack_queries(query_embeddings, check_norm)
         bits = self._where_bits(where)
+        if n_results <= _native.MAX_K and self.f32_exact and self.dtype == torch.float32 and q.shape[0] > 64:
+            # exact float32 scores whatever the batch size (MMRAG_F32_EXACT_SEARCH): 64 queries per scan keep the exact
+            # float32 matrix instruction; bigger batches would take the bf16-split path of csrc/search.hip
+            parts = [_native.cosine_topk(q[i:i + 64], self._matrix, self._n, self.dim, n_results, alive_bits=bits)
+                     for i in range(0, q.shape[0], 64)]
+            return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
         if n_results <= _native.MAX_K:
             need = _native.cosine_topk_workspace_bytes(q.shape[0], self._n, n_results)
             if self._search_ws is None or self._search_ws.numel() < need:

@@ -378,3 +378,37 @@ def test_fp32_split_random_and_exact_integers(N, B, n, d):
     qi = g.integers(-3, 4, size=(B, d)).astype(np.float32)
     s, r, es, er = run(N, qi, ci, 5, torch.float32)
     assert np.array_equal(s, es) and np.array_equal(r, er)                     # small integers: hi term exact, lo = 0
+
+
+def test_fp32_scores_do_not_depend_on_the_batch_when_asked(N):
+    """a float32 collection scores batches of more than 64 queries from a bf16 split (<= 4e-5 off), smaller
+    ones exactly, so a query's score depended on how many requests the dispatcher batched with it.
+    MMRAG_F32_EXACT_SEARCH (VectorIndex.f32_exact) keeps the exact float32 path for every batch size: a query's row of
+    the result is bit for bit the same alone, among 65 and among 256.  Default mode: ids still equal on data whose
+    score gaps exceed the split's error (the tie rule -- lower row first -- is the same on both paths)."""
+    from multimodal_rag_amd.index import VectorIndex
+
+    d, n = 384, 60_000
+    c = unit_rows(n, d, 91)
+    c[1000] = c[7]                      # an exact tie: row 7 must come first on every path
+    q = unit_rows(256, d, 92)
+    q[0] = c[7]
+    ix = VectorIndex(d, dtype=torch.float32, device="cuda:0", capacity=n)
+    ix.add_rows_device(torch.from_numpy(c).cuda(), None, None, [f"doc_a_text_{i}" for i in range(n)])
+    qd = torch.from_numpy(q).cuda()
+    ix.f32_exact = True
+    s1, r1 = ix.search(qd[:1], 5)
+    s65, r65 = ix.search(qd[:65], 5)
+    s256, r256 = ix.search(qd, 5)
+    assert torch.equal(s1, s65[:1]) and torch.equal(r1, r65[:1])
+    assert torch.equal(s65, s256[:65]) and torch.equal(r65, r256[:65])
+    assert r256[0, :2].tolist() == [7, 1000]
+    es, er = O.cosine_topk(q, c, 5)
+    assert np.abs(s256.cpu().numpy() - es).max() <= 2e-6
+    ix.f32_exact = False                # the default: the split path above 64 queries
+    s, r = ix.search(qd, 5)
+    assert np.abs(s.cpu().numpy() - s256.cpu().numpy()).max() <= 4e-5
+    gaps = np.abs(np.diff(es, axis=1)).min(axis=1)
+    clear = np.nonzero(gaps > 2e-4)[0]  # queries whose top-5 scores are further apart than the split's error
+    assert clear.size > 100 and np.array_equal(r.cpu().numpy()[clear], r256.cpu().numpy()[clear])
+    assert r[0, :2].tolist() == [7, 1000]

@@ -30,7 +30,11 @@ def bench(B, n, d, dtype, k=5, iters=20, dbg=0):
     ms = e0.elapsed_time(e1) / iters
     byt = n * ld * c.element_size()
     fl = 2.0 * B * n * d
-    print(f"B={B} n={n} d={d} {dtype} k={k}{' [slab-ring kernel]' if dbg else ''}: {ms*1e3:.1f} us  {byt/ms/1e6:.1f} GB/s  {fl/ms/1e9:.1f} TFLOP/s  {B/ms*1e3:.0f} q/s", flush=True)
+    tag = ""
+    if dbg & N.DBG_NO_QS: tag = " [slab-ring kernel]"
+    elif dbg & N.DBG_OLD_QS: tag = " [three-launch query-stationary kernel]"
+    elif dbg & N.DBG_FORCE_QS: tag = " [walk kernel forced]"
+    print(f"B={B} n={n} d={d} {dtype} k={k}{tag}: {ms*1e3:.1f} us  {byt/ms/1e6:.1f} GB/s  {fl/ms/1e9:.1f} TFLOP/s  {B/ms*1e3:.0f} q/s", flush=True)
 
 if __name__ == "__main__":
     torch.cuda.init()
@@ -38,13 +42,15 @@ if __name__ == "__main__":
     print("# C3 (1M x 768 fp16): whole corpus, then the per-GPU shards of N=2,4,8")
     for n in (1_000_000, 500_000, 250_000, 125_000):
         bench(256, n, 768, f16); bench(256, n, 768, f16, dbg=N.DBG_NO_QS)
+        bench(256, n, 768, f16, dbg=N.DBG_FORCE_QS); bench(256, n, 768, f16, dbg=N.DBG_FORCE_QS | N.DBG_OLD_QS)
     print("# C2 (100k x 384 fp32, one GPU)")
     for B in (1, 32, 256): bench(B, 100_000, 384, f32)
     print("# C4 (600k x 512 fp16): whole and 1/8")
     for n in (600_000, 75_000):
-        bench(256, n, 512, f16); bench(256, n, 512, f16, dbg=N.DBG_NO_QS)
+        bench(256, n, 512, f16); bench(256, n, 512, f16, dbg=N.DBG_NO_QS); bench(256, n, 512, f16, dbg=N.DBG_FORCE_QS)
     print("# C5 (10M x 768 fp16, B=1024): the 1/8 shard")
     bench(1024, 1_250_000, 768, f16); bench(1024, 1_250_000, 768, f16, dbg=N.DBG_NO_QS)
+    bench(1024, 1_250_000, 768, f16, dbg=N.DBG_OLD_QS)
     print("# other batch sizes / depths at 1M x 768")
     for B in (1, 32, 128): bench(B, 1_000_000, 768, f16)
     for B in (32, 128, 256):
