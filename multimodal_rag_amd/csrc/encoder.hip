@@ -478,10 +478,16 @@ __device__ inline void interleave_reads_mfmas() {
     }
 }
 
-template <int NWF, int NWT>  // waves along the features x waves along the tokens of the 256x256 tile
+// MS: MFMA shape.  32 = v_mfma_f32_32x32x16_f16 (a wave's 128 x 64 outputs as 4 x 2 tiles of 32 x 32), 16 =
+// v_mfma_f32_16x16x32_f16 (8 x 4 tiles of 16 x 16: the same output tile, accumulator registers and LDS bytes per flop;
+// the chip holds a higher clock on it under load -- MI355X_MICROARCH.md, DVFS give-back item 7; bare loops on this
+// part: 1.88 vs 1.71 PFLOP/s).  The fragment reads of a 32-deep k-step are split over its two halves (features 0-63
+// first, 64-127 second), so the two sets of fragments in flight take 64 registers, not 96.
+template <int NWF, int NWT, int MS = 32>  // waves along the features x waves along the tokens of the 256x256 tile
 __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(const LinearParams p, const int n_tiles,
                                                                             const int tiles_f) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(MS == 32 || MS == 16, "MFMA shape");
     constexpr int BF = 256, BT = 256;
     constexpr int NW = NWF * NWT;
     constexpr int FT = BF / (32 * NWF);   // MFMA tiles along the features per wave (pairs of them interleave)
@@ -489,8 +495,9 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
     constexpr int WAVE_F = BF / NWF, WAVE_T = BT / NWT;
     constexpr int STAGE = (BF + BT) * SLAB;
     constexpr int PW = 64 / NW;           // DMA pieces per wave per ring item: first half of the waves fetch W, second half x
-    constexpr int STORES = (FT / 2) * TT * 16;
+    constexpr int STORES = MS == 32 ? (FT / 2) * TT * 16 : 2 * 4 * 4;   // store instructions of one epilogue, per wave
     static_assert(FT % 2 == 0 && PW >= 4, "layout");
+    static_assert(MS == 32 || (WAVE_F == 128 && WAVE_T == 64), "the 16x16x32 form is written for 128 x 64 per wave");
     constexpr int STORES_WAIT = STORES < 63 ? STORES : 63;  // vmcnt is a 6-bit counter
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
@@ -510,13 +517,17 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int prow = (lw * PW + i) * 8 + (lane >> 3);
-        const int srow = loads_w ? ((prow & ~63) | ((prow & 31) << 1) | ((prow >> 5) & 1)) : prow;
+        // 16x16x32: FOUR features per lane: inside each block of 64 rows, row 16 b + j <-> feature 4 j + b
+        const int srow = !loads_w ? prow
+                         : (MS == 32 ? ((prow & ~63) | ((prow & 31) << 1) | ((prow >> 5) & 1))
+                                     : ((prow & ~63) | ((prow & 15) << 2) | ((prow >> 4) & 3)));
         src_off[i] = __umul24((unsigned)srow, RB) + (unsigned)(((lane & 7) ^ ((prow >> 1) & 7)) * 16);   // (K < 2^23)
     }
     // piece i = 2q + (i&1): LDS rows advance by 16q
     auto piece_src_rows = [&](int i) -> int {
         const int q = i >> 1;
         if (!loads_w) return 16 * q;
+        if constexpr (MS == 16) return (q >> 2) * 64 + (q & 3);   // 16 LDS rows on = the next feature of the four; 64 = next block
         return (q >> 2) * 64 + ((q >> 1) & 1) + (q & 1) * 32;   // 16 LDS rows on = 32 features on; 32 rows on = the odd features; 64 = next block
     };
     char *const my_dst = smem + (loads_w ? 0 : BF * SLAB) + lw * PW * 1024;
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
     };
     // acc[a][b]: a = 2*block + parity; register r <-> token 8*(r/4) + 4*h + r%4 of token tile b; lane j <-> features
     // 64*block + 2j + parity
-    f32x16_t acc[FT][TT];
+    f32x16_t acc[MS == 32 ? FT : 1][MS == 32 ? TT : 1];
     auto mma = [&](const half8_t(&w_)[FT], const half8_t(&x_)[TT]) {
 #pragma unroll
         for (int a = 0; a < FT; ++a)
@@ -582,6 +593,33 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x_[b], w_[a], acc[a][b], 0, 0, 0);
     };
     auto interleave = [&]() { interleave_reads_mfmas<FT + TT, FT * TT>(); };
+
+    // ---- 16x16x32 form: lane (c = lane & 15, g4 = lane >> 4); a 32-deep k-step s of a slab reads chunk (4 s + g4) ^ sw
+    // of row c of every 16-row block.  acc16[fb][tb]: feature block fb (LDS rows wf*128 + 16 fb ...), token block tb;
+    // register r <-> token 16 tb + 4 g4 + r, lane c <-> LDS row c of the block (feature 64 (fb/4) + 4c + fb%4).
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int sw16 = (c16 >> 1) & 7;
+    const int w16_base = (wf * WAVE_F + c16) * SLAB, x16_base = BF * SLAB + (wt_ * WAVE_T + c16) * SLAB;
+    half8_t gw[2][4], gx[2][4];           // two sets of four W fragments (half a k-step) and of four x fragments (a k-step)
+    f32x4_t acc16[MS == 16 ? 8 : 1][MS == 16 ? 4 : 1];
+    auto load_w16 = [&](half8_t(&w_)[4], const char *st, int step, int half) {
+        const int off = ((4 * step + g4) ^ sw16) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w_[i] = *(const half8_t *)(st + w16_base + (4 * half + i) * (16 * SLAB) + off);
+    };
+    auto load_x16 = [&](half8_t(&x_)[4], const char *st, int step) {
+        const int off = ((4 * step + g4) ^ sw16) * 16;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x_[b] = *(const half8_t *)(st + x16_base + b * (16 * SLAB) + off);
+    };
+    auto mma16 = [&](const half8_t(&w_)[4], const half8_t(&x_)[4], auto half_c) {
+        constexpr int half = decltype(half_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc16[4 * half + i][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x_[b], w_[i], acc16[4 * half + i][b], 0, 0, 0);
+    };
 
     int v = blockIdx.x;
     const char *cur_base, *nxt_base;
@@ -598,25 +636,52 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
     for (; v < n_tiles; v += (int)gridDim.x) {
         int f0, t0;
         tile_origin(v, f0, t0);
+        if constexpr (MS == 32) {
 #pragma unroll
-        for (int a = 0; a < FT; ++a)
+            for (int a = 0; a < FT; ++a)
 #pragma unroll
-            for (int b = 0; b < TT; ++b)
+                for (int b = 0; b < TT; ++b)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.0f;
+                    for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.0f;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc16[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 
-        load(fw[0], fx[0], smem + (g & 1) * STAGE, 0);
+        if constexpr (MS == 32) load(fw[0], fx[0], smem + (g & 1) * STAGE, 0);
+        else {
+            load_x16(gx[0], smem + (g & 1) * STAGE, 0);
+            load_w16(gw[0], smem + (g & 1) * STAGE, 0, 0);
+        }
         for (int it = 0; it < nk; ++it, ++g) {
             const char *st = smem + (g & 1) * STAGE;
-            load(fw[1], fx[1], st, 1);
-            mma(fw[0], fx[0]);
-            interleave();
-            load(fw[0], fx[0], st, 2);
-            mma(fw[1], fx[1]);
-            interleave();
-            load(fw[1], fx[1], st, 3);
-            mma(fw[0], fx[0]);
-            interleave();
+            if constexpr (MS == 32) {
+                load(fw[1], fx[1], st, 1);
+                mma(fw[0], fx[0]);
+                interleave();
+                load(fw[0], fx[0], st, 2);
+                mma(fw[1], fx[1]);
+                interleave();
+                load(fw[1], fx[1], st, 3);
+                mma(fw[0], fx[0]);
+                interleave();
+            } else {
+                // quarter 0: k-step 0, features 0-63; fetch the W fragments of features 64-127
+                load_w16(gw[1], st, 0, 1);
+                mma16(gw[0], gx[0], std::integral_constant<int, 0>{});
+                interleave_reads_mfmas<4, 16>();
+                // quarter 1: k-step 0, features 64-127; fetch k-step 1 (x and the first W half)
+                load_x16(gx[1], st, 1);
+                load_w16(gw[0], st, 1, 0);
+                mma16(gw[1], gx[0], std::integral_constant<int, 1>{});
+                interleave_reads_mfmas<8, 16>();
+                // quarter 2: k-step 1, features 0-63
+                load_w16(gw[1], st, 1, 1);
+                mma16(gw[0], gx[1], std::integral_constant<int, 0>{});
+                interleave_reads_mfmas<4, 16>();
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of this stage are complete
             // item g+1 has landed.  vmcnt retires in issue order: in the first iteration after an epilogue the
             // stores of the previous tile are YOUNGER than item g+1 and may stay in flight
@@ -628,9 +693,19 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
                 if (k2 < nk) issue(cur_base, cur_bytes, g & 1, k2);
                 else if (nxt_bytes != 0) issue(nxt_base, nxt_bytes, g & 1, k2 - nk);
             }
-            if (it + 1 < nk) load(fw[0], fx[0], smem + ((g + 1) & 1) * STAGE, 0);
-            mma(fw[1], fx[1]);
-            interleave();
+            if constexpr (MS == 32) {
+                if (it + 1 < nk) load(fw[0], fx[0], smem + ((g + 1) & 1) * STAGE, 0);
+                mma(fw[1], fx[1]);
+                interleave();
+            } else {
+                // quarter 3: k-step 1, features 64-127; fetch k-step 0 of the next slab
+                if (it + 1 < nk) {
+                    load_x16(gx[0], smem + ((g + 1) & 1) * STAGE, 0);
+                    load_w16(gw[0], smem + ((g + 1) & 1) * STAGE, 0, 0);
+                }
+                mma16(gw[1], gx[1], std::integral_constant<int, 1>{});
+                interleave_reads_mfmas<8, 16>();
+            }
         }
         cur_base = nxt_base;
         cur_bytes = nxt_bytes;
@@ -657,6 +732,55 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
             constexpr int ACT = decltype(act_tag)::value;
             constexpr bool RES = decltype(res_tag)::value;
             constexpr bool RAGGED = decltype(ragged_tag)::value;
+            if constexpr (MS == 16) {
+                // lane (c, g4) holds, in the four feature blocks of a 64-feature group, the ADJACENT features 4c .. 4c+3
+                // (the W rows were interleaved that way at DMA time) of tokens 16 tb + 4 g4 + r: an 8-byte store per lane,
+                // sixteen lanes = one whole 128-byte line, four token rows per instruction -- half the store instructions
+                // of the 32x32x16 form (with two features per lane and 64-byte segments this epilogue cost 8 us more)
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const int c16e = (int)(lane_e & 15u), g4e = (int)(lane_e >> 4);
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {
+                    const int fcol = f0 + wf * WAVE_F + grp * 64 + 4 * c16e;
+                    const bool f_ok = fcol < p.N;   // N % 4 == 0 (the launcher's condition)
+                    const unsigned voff = f_ok ? (unsigned)(4 * g4e) * row_b + (unsigned)fcol * 2u : 0x80000000u;
+                    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias != nullptr && f_ok) bias4 = *(const f32x4_t *)(p.bias + fcol);
+                    unsigned rv0[4][4], rv1[4][4];   // the residual's two feature pairs (as scalars: see below)
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const unsigned ro = wrow_b + (unsigned)(tb * 16 + r) * row_b;
+                                // (element by element into scalars: through a 2-vector -- __builtin_bit_cast of the builtin's
+                                // result, or element stores into one -- hipcc loaded ONE dword and used it for both halves)
+                                const auto raw = RAGGED ? __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff + ro, 0, 0)
+                                                        : __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, ro, 0);
+                                rv0[tb][r] = raw[0];
+                                rv1[tb][r] = raw[1];
+                            }
+                    }
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned ro = wrow_b + (unsigned)(tb * 16 + r) * row_b;
+                            half2_t lo = f2h(act_apply<ACT>(acc16[4 * grp][tb][r] + bias4[0]),
+                                             act_apply<ACT>(acc16[4 * grp + 1][tb][r] + bias4[1]));
+                            half2_t hi = f2h(act_apply<ACT>(acc16[4 * grp + 2][tb][r] + bias4[2]),
+                                             act_apply<ACT>(acc16[4 * grp + 3][tb][r] + bias4[3]));
+                            if constexpr (RES) {
+                                lo = lo + __builtin_bit_cast(half2_t, rv0[tb][r]);
+                                hi = hi + __builtin_bit_cast(half2_t, rv1[tb][r]);
+                            }
+                            const u32x2_t o = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                            if constexpr (RAGGED) __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff + ro, 0, 2);
+                            else __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, ro, 2);
+                        }
+                }
+                return;
+            }
 #pragma unroll
             for (int blk = 0; blk < FT / 2; ++blk) {
                 const int fcol = f0 + wf * WAVE_F + blk * 64 + 2 * r32e;   // this lane's feature pair
@@ -682,7 +806,9 @@ __global__ __launch_bounds__(64 * NWF *NWT, 1) void linear_persistent_kernel(con
                     for (int r = 0; r < 16; ++r) {
                         const unsigned ro = wrow_b + (unsigned)(b * 32 + 8 * (r >> 2) + (r & 3)) * row_b;
                         // (the activated value is rounded to fp16 before the residual add, as in linear_kernel)
-                        half2_t o = f2h(act_apply<ACT>(acc[2 * blk][b][r] + bias2.x), act_apply<ACT>(acc[2 * blk + 1][b][r] + bias2.y));
+                        half2_t o;
+                        if constexpr (MS == 32)
+                            o = f2h(act_apply<ACT>(acc[2 * blk][b][r] + bias2.x), act_apply<ACT>(acc[2 * blk + 1][b][r] + bias2.y));
                         if constexpr (RES) o = o + __builtin_bit_cast(half2_t, rv[b][r]);
                         if constexpr (RAGGED)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, voff + ro, 0, 2);
@@ -1330,7 +1456,11 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
             linear_kernel<256, 256, 4, 4, 2><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
         else if (K >= 128 && N % 2 == 0 && !(dbg & DBG_LINEAR_NO_PERSIST)) {
             const unsigned grid = (unsigned)(big_tiles < cus ? big_tiles : cus);
-            linear_persistent_kernel<2, 4><<<grid, 512, 0, s>>>(p, (int)big_tiles, (int)tiles_f);
+            // 16x16x32 MFMAs: 5.3-5.9 % over the 32x32x16 form on every encoder shape (tools/linear_vs_rocblas.py, one
+            // process; main loop alone 6-7.6 %), as fast as hipBLASLt at K = 768 with the bias fused.  Its stores take four
+            // features per lane, hence N % 4.
+            if (!(dbg & DBG_LINEAR_MFMA32) && N % 4 == 0) linear_persistent_kernel<2, 4, 16><<<grid, 512, 0, s>>>(p, (int)big_tiles, (int)tiles_f);
+            else linear_persistent_kernel<2, 4, 32><<<grid, 512, 0, s>>>(p, (int)big_tiles, (int)tiles_f);
         } else
             linear_kernel<256, 256, 4, 4, 2, true><<<(unsigned)big_tiles, 1024, 0, s>>>(p);
     } else {

@@ -39,6 +39,7 @@ constexpr unsigned DBG_LINEAR_PLAIN = 1u, DBG_LINEAR_NO_SMALL = 2u, DBG_LINEAR_N
 // timing-only ablations of the persistent linear kernel (results are wrong): stores dropped by the buffer unit, no epilogue at all
 constexpr unsigned DBG_LINEAR_DROP_STORES = 8u, DBG_LINEAR_SKIP_EPILOGUE = 16u;
 constexpr unsigned DBG_LINEAR_X_SAME = 128u;
+constexpr unsigned DBG_LINEAR_MFMA32 = 8192u;   // persistent GEMM on v_mfma_f32_32x32x16_f16 instead of 16x16x32 (A/B of the MFMA shape)
 constexpr unsigned DBG_LINEAR_SMALL32 = 256u;
 constexpr unsigned DBG_ENCODER_LN_PASSES = 512u;
 constexpr unsigned DBG_ATTENTION_STREAMED = 4096u;   // attention: the double-buffered key-tile loop also for short sequences (A/B)

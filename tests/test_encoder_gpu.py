@@ -102,6 +102,30 @@ def test_linear_persistent_exact_integers(N):
     assert np.array_equal(out.float().cpu().numpy(), x @ w.T + (np.arange(Nf) % 4) + res)
 
 
+@pytest.fixture
+def mfma32(N):
+    """the persistent GEMM on v_mfma_f32_32x32x16_f16 (developer switch 8192: the A/B partner of the default 16x16x32 form)"""
+    import ctypes
+
+    L = N.lib()
+    L.mmrag_internal_set_debug.argtypes = [ctypes.c_uint]
+    L.mmrag_internal_set_debug(8192)
+    yield
+    L.mmrag_internal_set_debug(0)
+
+
+@pytest.mark.parametrize("M,K,Nf", [(22000, 768, 768), (8300, 128, 2304), (17000, 192, 1000), (65536, 768, 2304)])
+@pytest.mark.parametrize("act,with_resid", [(0, False), (1, False), (0, True), (2, True)])
+def test_linear_persistent_32x32x16(N, mfma32, M, K, Nf, act, with_resid):
+    test_linear(N, M, K, Nf, act, with_resid)
+
+
+def test_linear_persistent_32x32x16_exact_integers(N, mfma32):
+    """(the default 16x16x32 form -- W rows interleaved four ways at DMA time, 8-byte stores -- is what
+    test_linear_persistent_exact_integers and test_linear_one_tile_per_cu_and_more run)"""
+    test_linear_persistent_exact_integers(N)
+
+
 def test_linear_exact_integers(N):
     """integer data is exact in fp16 x fp16 -> fp32: catches any fragment / epilogue index swap"""
     g = np.random.default_rng(0)

@@ -6,8 +6,8 @@ import torch
 from multimodal_rag_amd import _native as N
 L = N.lib()
 L.mmrag_internal_set_debug.argtypes = [ctypes.c_uint]
-VARIANTS = {"default": 0, "one-tile-per-wg": 4, "drop-stores": 8, "no-epilogue": 16, "x-same": 128}
-CHECKED = ("default", "one-tile-per-wg")
+VARIANTS = {"default": 0, "mfma32": 8192, "one-tile-per-wg": 4, "no-epilogue": 16, "mfma32+no-epilogue": 8192 + 16}
+CHECKED = ("default", "mfma32", "one-tile-per-wg")
 def t(fn, iters=800):   # ~0.2 s per measurement: the board throttles after a few ms of this load
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
