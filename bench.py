@@ -140,6 +140,22 @@ def served_leg(dev, corpus, n_rows: int, seconds: float = 2.0):
             k = (k + 256) % 3840
         out["batch_query_256"] = {"queries_per_s": round(n_q / (time.perf_counter() - t0), 1), "calls": n_q // 256,
                                   "stage_mean_ms": {k: v["mean_ms"] for k, v in tracing.snapshot().items()}}
+        # (a') the same call from three concurrent callers (a server's normal state): one caller's tokenisation and result
+        # building overlap the other callers' GPU time (the tokenizer is native and drops the GIL, the GPU wait drops it too)
+        t_end, t0 = time.perf_counter() + seconds, time.perf_counter()
+        done3 = [0]
+
+        async def batch_caller(j):
+            k3 = (j * 1280) % 3840
+            while time.perf_counter() < t_end:
+                res = await m.batch_query(texts[k3:k3 + 256], n_results=TOPK)
+                assert len(res) == 256 and len(res[0]["ids"]) == TOPK
+                done3[0] += 256
+                k3 = (k3 + 256) % 3840
+
+        await asyncio.gather(*[batch_caller(j) for j in range(3)])
+        out["batch_query_256_x3_callers"] = {"queries_per_s": round(done3[0] / (time.perf_counter() - t0), 1),
+                                              "calls": done3[0] // 256}
         # (b) query() x 64 concurrent callers through the dispatcher
         disp = m.enable_dynamic_batching(max_batch=256, max_wait_ms=1.0)
         stop_at = time.perf_counter() + seconds

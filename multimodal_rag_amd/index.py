@@ -16,6 +16,7 @@ No vector arithmetic happens in this file: torch provides device buffers and cop
 from __future__ import annotations
 
 import logging
+import operator
 import threading
 from typing import Any, Callable, Dict, List, Optional, Sequence
 
@@ -435,17 +436,33 @@ class VectorIndex:
         out: Dict[str, Any] = {"ids": [], "distances": [] if dist_l is not None else None,
                                "metadatas": [] if want_m else None, "documents": [] if want_d else None,
                                "embeddings": [] if want_e else None}
-        for b, row in enumerate(rows_l):
-            hit = [r for r in row if r >= 0]            # misses (-1) only trail
-            out["ids"].append([ids_t[r] for r in hit])
+        # every table is read with ONE itemgetter call over all hits of the batch (a C loop), then cut per query:
+        # B x k Python-level index operations and dict() calls were most of the host time of a 256-query batch
+        counts = [k_ if row[-1] >= 0 else sum(1 for r in row if r >= 0) for row in rows_l for k_ in (len(row),)]
+        flat = [r for row, c in zip(rows_l, counts) for r in row[:c]]            # misses (-1) only trail
+        if len(flat) == 1:
+            pick = lambda table: (table[flat[0]],)                               # noqa: E731  (itemgetter(x) alone returns the item)
+        elif flat:
+            getter = operator.itemgetter(*flat)
+            pick = lambda table: getter(table)                                   # noqa: E731
+        else:
+            pick = lambda table: ()                                              # noqa: E731
+        ids_f = pick(ids_t)
+        metas_f = list(map(dict, pick(metas_t))) if want_m else None
+        docs_f = pick(docs_t) if want_d else None
+        lo = 0
+        for b, c in enumerate(counts):
+            hi = lo + c
+            out["ids"].append(list(ids_f[lo:hi]))
             if dist_l is not None:
-                out["distances"].append(dist_l[b][:len(hit)])
+                out["distances"].append(dist_l[b][:c])
             if want_m:
-                out["metadatas"].append([dict(metas_t[r]) for r in hit])
+                out["metadatas"].append(metas_f[lo:hi])
             if want_d:
-                out["documents"].append([docs_t[r] for r in hit])
+                out["documents"].append(list(docs_f[lo:hi]))
             if want_e:
-                out["embeddings"].append(self._fetch(hit, emb_src))
+                out["embeddings"].append(self._fetch(flat[lo:hi], emb_src))
+            lo = hi
         return out
 
     def ids_of_rows(self, rows: Sequence[int]) -> List[str]:
