@@ -102,6 +102,80 @@ __global__ __launch_bounds__(256) void mfma_peak16_kernel(const half8_t *__restr
 #endif
 }
 
+
+// Developer probe: cycles per v_mfma_f32_16x16x32_f16 in loops that add, one at a time, what the search walk's k-step has
+// around its MFMAs.  MODE 0: eight MFMAs per statement, A and B in arch VGPRs; 1: B in the accumulator file; 2: B rotating
+// over 16 fragments (64 registers) of the accumulator file; 3: (2) + the statement's v_xad and two ds_read_b128 of the
+// NEXT statement's A fragments; 4: (3) + the closing s_waitcnt lgkmcnt(0).  stamps[2 wg] = shader cycles (s_memtime),
+// stamps[2 wg + 1] = 100 MHz ticks (s_memrealtime) of wave 0's loop.
+#define MMRAG_PROBE_8(QC, Q0, Q1, Q2, Q3, PRE, POST)                                                                  \
+    asm volatile(PRE "v_mfma_f32_16x16x32_f16 %[d0], %[a0], %[" Q0 "], %[d0]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d1], %[a0], %[" Q1 "], %[d1]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d2], %[a0], %[" Q2 "], %[d2]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d3], %[a0], %[" Q3 "], %[d3]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d4], %[a1], %[" Q0 "], %[d4]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d5], %[a1], %[" Q1 "], %[d5]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d6], %[a1], %[" Q2 "], %[d6]\n\t"                                     \
+                     "v_mfma_f32_16x16x32_f16 %[d7], %[a1], %[" Q3 "], %[d7]" POST                                    \
+                 : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [d4] "+v"(d4), [d5] "+v"(d5),           \
+                   [d6] "+v"(d6), [d7] "+v"(d7), [n0] "=&v"(n0), [n1] "=&v"(n1), [t] "=&v"(tmp)                        \
+                 : [a0] "v"(a0), [a1] "v"(a1), [q0] QC(q0), [q1] QC(q1), [q2] QC(q2), [q3] QC(q3), [lo] "v"(lo),       \
+                   [st] "s"(st))
+template <int MODE>
+__device__ __forceinline__ void probe_stmt(f32x4_t &d0, f32x4_t &d1, f32x4_t &d2, f32x4_t &d3, f32x4_t &d4, f32x4_t &d5,
+                                           f32x4_t &d6, f32x4_t &d7, const half8_t a0, const half8_t a1, const half8_t q0,
+                                           const half8_t q1, const half8_t q2, const half8_t q3, half8_t &n0, half8_t &n1,
+                                           const unsigned lo, const unsigned st) {
+    unsigned tmp;
+    if constexpr (MODE == 0) MMRAG_PROBE_8("v", "q0", "q1", "q2", "q3", "", "");
+    else if constexpr (MODE <= 2) MMRAG_PROBE_8("a", "q0", "q1", "q2", "q3", "", "");
+    else if constexpr (MODE == 3)
+        MMRAG_PROBE_8("a", "q0", "q1", "q2", "q3",
+                      "v_xad_u32 %[t], %[lo], 64, %[st]\n\tds_read_b128 %[n0], %[t]\n\tds_read_b128 %[n1], %[t] offset:2048\n\t", "");
+    else
+        MMRAG_PROBE_8("a", "q0", "q1", "q2", "q3",
+                      "v_xad_u32 %[t], %[lo], 64, %[st]\n\tds_read_b128 %[n0], %[t]\n\tds_read_b128 %[n1], %[t] offset:2048\n\t",
+                      "\n\ts_waitcnt lgkmcnt(0)");
+    if constexpr (MODE < 3) { n0 = a0; n1 = a1; }
+}
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const half8_t *__restrict__ seed, float *__restrict__ out,
+                                                            int iters, long long *__restrict__ stamps) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) half8_t tile[4096];   // 64 KiB of fragments
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += 256) tile[i] = seed[i & 255];
+    __syncthreads();
+    half8_t q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q[j] = seed[(17 * lane + 16 * j) & 255];
+    half8_t a0 = seed[lane], a1 = seed[(64 + lane) & 255], b0 = a1, b1 = a0;
+    f32x4_t c[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = f32x4_t{};
+    const unsigned lo = (unsigned)(size_t)(__attribute__((address_space(3))) void *)tile + lane * 16;
+    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        const unsigned st = (unsigned)((it & 7) * 4096);
+        constexpr int R = MODE >= 2 ? 4 : 0;   // B fragments rotate over q[0..15] / stay q[0..3]
+        probe_stmt<MODE>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], a0, a1, q[0], q[1], q[2], q[3], b0, b1, lo, st);
+        probe_stmt<MODE>(c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], b0, b1, q[R], q[R + 1], q[R + 2], q[R + 3], a0, a1, lo, st + 1024);
+        probe_stmt<MODE>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], a0, a1, q[2 * R], q[2 * R + 1], q[2 * R + 2], q[2 * R + 3], b0, b1, lo, st + 2048);
+        probe_stmt<MODE>(c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], b0, b1, q[3 * R], q[3 * R + 1], q[3 * R + 2], q[3 * R + 3], a0, a1, lo, st + 3072);
+    }
+    const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_nop 15\n\ts_nop 7");
+    f32x4_t t = c[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) t += c[j];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = t[0] + t[1] + t[2] + t[3];
+    if (threadIdx.x == 0 && stamps) {
+        stamps[2 * blockIdx.x] = (long long)(t1c - t0c);
+        stamps[2 * blockIdx.x + 1] = (long long)(t1r - t0r);
+    }
+#endif
+}
+
 }  // namespace mmrag_impl
 using namespace mmrag_impl;
 
@@ -157,6 +231,22 @@ int mmrag_bench_mfma_f16(const void *seed, float *out, int iters, int64_t *flops
     mfma_peak_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half8_t *)seed, out, iters);
     MMRAG_CHECK_HIP(hipGetLastError());
     if (flops) *flops = (int64_t)grid * 4 /*waves*/ * (int64_t)iters * 4 /*MFMAs*/ * (2LL * 32 * 32 * 16);
+    return MMRAG_OK;
+}
+
+// developer probe (tools/mfma_probe.py): 32 MFMAs per iteration and wave; not part of the reference-facing surface
+int mmrag_internal_mfma_probe(const void *seed, float *out, int iters, int mode, long long *stamps, void *stream) {
+    MMRAG_CHECK_ARG(seed && out && iters > 0 && mode >= 0 && mode <= 4, "mfma_probe: bad arguments");
+    const int grid = num_cus();
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+    case 0: mfma_probe_kernel<0><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 1: mfma_probe_kernel<1><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 2: mfma_probe_kernel<2><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 3: mfma_probe_kernel<3><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    default: mfma_probe_kernel<4><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    }
+    MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;
 }
 

@@ -81,8 +81,8 @@ constexpr WRing qsw_ring(int NK, int K, int MS) {
 // stationary Q fragments sit in the accumulator file ("a") for the first 64 fragments and in arch VGPRs ("v") for the
 // rest: a wave alone on its SIMD owns all 512 registers.
 //
-// The fragment address is made inside the statement: v_xad_u32 = (lane constant ^ k-step term) + stage base (an
-// SGPR).  Left to hipcc, the four XOR variants of the lane constant and four stage addresses stay live across the tile
+// 32x32x16: the fragment address is made inside the statement: v_xad_u32 = (lane constant ^ k-step term) + stage base
+// (an SGPR); 16x16x32: two addresses per ring stage (qsw_stage_addr), made with the stage's last statement.  Left to hipcc, the four XOR variants of the lane constant and four stage addresses stay live across the tile
 // (eight VGPRs that the Q fragments need: it spilled two of those instead, and a spill reload waits vmcnt(0)).
 //
 // 32x32x16: a statement is one 16-deep k-step of the wave's 64 rows x 64 queries: 2 row blocks x 2 query blocks.
@@ -119,28 +119,26 @@ __device__ __forceinline__ void qsw_stmt32(f32x16_t &c00, f32x16_t &c01, f32x16_
 // 16x16x32: a statement is HALF of a 32-deep k-step: two of the four 16-row blocks x all four 16-query blocks.  Each
 // 1 KiB A fragment (16 rows x 32 k) feeds four MFMAs; eight MFMAs of 16 cycles = the same 128 cycles per two reads.
 #define MMRAG_QSW_S16(MNEMONIC, QC, D0, D1, D2, D3, D4, D5, D6, D7, ACC)                                      \
-    asm volatile("v_xad_u32 %[t], %[lo], %[xc], %[st]\n\t"                                                    \
-                 "ds_read_b128 %[n0], %[t] offset:%[o0]\n\t"                                                  \
-                 "ds_read_b128 %[n1], %[t] offset:%[o1]\n\t" MNEMONIC " %[d0], %[a0], %[q0], " D0 "\n\t"      \
+    asm volatile("ds_read_b128 %[n0], %[ad] offset:%[o0]\n\t"                                                 \
+                 "ds_read_b128 %[n1], %[ad] offset:%[o1]\n\t" MNEMONIC " %[d0], %[a0], %[q0], " D0 "\n\t"     \
                  MNEMONIC " %[d1], %[a0], %[q1], " D1 "\n\t" MNEMONIC " %[d2], %[a0], %[q2], " D2 "\n\t"      \
                  MNEMONIC " %[d3], %[a0], %[q3], " D3 "\n\t" MNEMONIC " %[d4], %[a1], %[q0], " D4 "\n\t"      \
                  MNEMONIC " %[d5], %[a1], %[q1], " D5 "\n\t" MNEMONIC " %[d6], %[a1], %[q2], " D6 "\n\t"      \
                  MNEMONIC " %[d7], %[a1], %[q3], " D7 "\n\t"                                                  \
                  "s_waitcnt lgkmcnt(0)"                                                                       \
                  : [d0] ACC(d0), [d1] ACC(d1), [d2] ACC(d2), [d3] ACC(d3), [d4] ACC(d4), [d5] ACC(d5),        \
-                   [d6] ACC(d6), [d7] ACC(d7), [n0] "=&v"(n0), [n1] "=&v"(n1), [t] "=&v"(tmp)                 \
+                   [d6] ACC(d6), [d7] ACC(d7), [n0] "=&v"(n0), [n1] "=&v"(n1)                                 \
                  : [a0] "v"(a0), [a1] "v"(a1), [q0] QC(q0), [q1] QC(q1), [q2] QC(q2), [q3] QC(q3),            \
-                   [lo] "v"(lo), [st] "s"(st), [xc] "i"(XC), [o0] "i"(OFF0), [o1] "i"(OFF1))
+                   [ad] "v"(adr), [o0] "i"(OFF0), [o1] "i"(OFF1))
 #define MMRAG_QSW_S16_ACC(MNEMONIC, QC)                                                                       \
     MMRAG_QSW_S16(MNEMONIC, QC, "%[d0]", "%[d1]", "%[d2]", "%[d3]", "%[d4]", "%[d5]", "%[d6]", "%[d7]", "+v")
 #define MMRAG_QSW_S16_FIRST(MNEMONIC, QC) MMRAG_QSW_S16(MNEMONIC, QC, "0", "0", "0", "0", "0", "0", "0", "0", "=&v")
 
-template <int DT, bool QA, bool FIRST, int XC, int OFF0, int OFF1, typename FT>
+template <int DT, bool QA, bool FIRST, int OFF0, int OFF1, typename FT>
 __device__ __forceinline__ void qsw_stmt16(f32x4_t &d0, f32x4_t &d1, f32x4_t &d2, f32x4_t &d3, f32x4_t &d4,
                                            f32x4_t &d5, f32x4_t &d6, f32x4_t &d7, const FT a0, const FT a1,
                                            const FT q0, const FT q1, const FT q2, const FT q3, FT &n0, FT &n1,
-                                           const unsigned lo, const unsigned st) {
-    unsigned tmp;
+                                           const unsigned adr) {
     if constexpr (FIRST) {
         static_assert(QA, "the first k-step's Q fragments live in the accumulator file");
         if constexpr (DT == MMRAG_F16) MMRAG_QSW_S16_FIRST("v_mfma_f32_16x16x32_f16", "a");
@@ -152,6 +150,33 @@ __device__ __forceinline__ void qsw_stmt16(f32x4_t &d0, f32x4_t &d1, f32x4_t &d2
         if constexpr (QA) MMRAG_QSW_S16_ACC("v_mfma_f32_16x16x32_bf16", "a");
         else MMRAG_QSW_S16_ACC("v_mfma_f32_16x16x32_bf16", "v");
     }
+}
+
+// the two fragment addresses of a ring stage on the 16x16x32 shape (the statements' 64-byte halves of a K-slab differ by
+// an XOR on the lane constant, everything else is in the read's immediate offset): two instructions per stage, not one
+// per statement -- every instruction between the MFMAs of a wave that is alone on its SIMD is matrix-pipe idle time
+__device__ __forceinline__ void qsw_stage_addr(unsigned &a_lo, unsigned &a_hi, const unsigned lo, const unsigned st) {
+    asm volatile("v_add_u32 %0, %2, %3\n\tv_xad_u32 %1, %2, 64, %3" : "=&v"(a_lo), "=&v"(a_hi) : "v"(lo), "s"(st));
+}
+
+// max of sixteen accumulator values as they are (finite or -inf): ONE statement -- between separate asm statements hipcc
+// puts a wait state each
+__device__ __forceinline__ float max16_raw(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7,
+                                           float x8, float x9, float x10, float x11, float x12, float x13, float x14,
+                                           float x15) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max_f32 %0, %0, %16"
+        : "=&v"(r)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x8), "v"(x9), "v"(x10), "v"(x11),
+          "v"(x12), "v"(x13), "v"(x14), "v"(x15));
+    return r;
 }
 
 constexpr int CP_SC1 = 16;   // cache-policy bit of the buffer builtins' aux operand: sc1 (L1 bypassed, L2 coherent at agent scope)
@@ -231,44 +256,61 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
     }
     auto c_off = [&](int i) -> unsigned { return i == 0 ? c_off0 : (c_off0 ^ 64u) + 8u * RBy; };
     // A ring stage is refilled piece by piece, one 1 KiB piece after every other statement (a burst backs up in the
-    // texture-address queue and four waves alone on their SIMDs pay every cycle of it).  `fill_*` describe the stage
-    // being refilled; stages past the end of this workgroup's walk are refilled through a zero-length descriptor
-    // (nothing is fetched), so the instruction stream and the vmcnt arithmetic have no tail cases.
-    int is_sg = 0, is_pos = 0;
+    // texture-address queue and four waves alone on their SIMDs pay every cycle of it).  Stages past the end of this
+    // workgroup's walk are refilled through a zero-length descriptor (nothing is fetched), so the instruction stream and
+    // the vmcnt arithmetic have no tail cases.
+    // Everything scalar here costs matrix-pipe time (one wave per SIMD: nothing else to issue from), so it is kept to
+    // one s_add (M0) and one s_movk (the K offset) per piece: which K-slabs a refill fetches (IS_SG) is a compile-time
+    // property of the statement it follows, the descriptor is made once per tile, and both constants are made where
+    // they are used -- left to itself hipcc hoists two dozen of them out of the tile loop into SGPRs, spills those into
+    // VGPR lanes and pays a v_readlane per piece.
+    int is_pos = 0;
     int fill_tile = bx;
     __amdgpu_buffer_rsrc_t fill_rsrc;
-    char *fill_lds;
-    int fill_k0;
-    auto next_fill = [&](int buf) {
+    typedef __attribute__((address_space(3))) char *lds_char_t;
+    const lds_char_t wave_lds = (lds_char_t)(lds_ptr_t)(smem + wave * (RB * 1024));
+    lds_char_t stage_lds = wave_lds;   // this wave's part of the ring stage being refilled
+    auto fill_open = [&]() {   // descriptor of the tile the next SPT refills fetch
         const bool real = (unsigned)fill_tile < (unsigned)p.n_tiles && !(p.dbg & DBG_QS_NO_DMA);   // (a ticket past the end: no tile)
         const long long row0 = real ? ((p.dbg & DBG_QS_DMA_L2) ? (long long)bx * R : (long long)fill_tile * R) : 0;
         const long long rows_left = p.n - row0;
         const unsigned c_bytes = real ? (unsigned)((rows_left < R ? rows_left : (long long)R) * (long long)RBy) : 0u;
         fill_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.corpus + (size_t)row0 * RBy), 0, c_bytes, 0x00020000);
-        fill_lds = smem + buf * STAGE + wave * (RB * 1024);
-        fill_k0 = is_sg * (G * SLAB);
-        if (++is_sg == SPT) {
-            is_sg = 0;
-            ++is_pos;
-            fill_tile = pos_tile(is_pos);
-        }
     };
-    auto issue_piece = [&](auto pi_c) {
-        constexpr int PI = decltype(pi_c)::value;
+    auto next_fill = [&](auto is_sg_c, int buf) {
+        constexpr int IS_SG = decltype(is_sg_c)::value;
+        if constexpr (IS_SG == 0) {
+            if (is_pos != 0) fill_tile = pos_tile(is_pos);
+            fill_open();
+            ++is_pos;
+        }
+        // (made opaque once per stage: hipcc then forms each piece's M0 as stage_lds + constant in one s_add and
+        // cannot turn the 24 sums into loop invariants)
+        stage_lds = wave_lds + buf * STAGE;
+        asm volatile("" : "+s"(stage_lds));
+    };
+    unsigned koff = 0;   // K offset of the piece pair being issued
+    auto issue_piece = [&](auto is_sg_c, auto pi_c) {
+        constexpr int IS_SG = decltype(is_sg_c)::value, PI = decltype(pi_c)::value;
         constexpr int g = PI / RB, i = PI % RB;
+        if constexpr (i == 0) asm volatile("s_movk_i32 %0, %1" : "=s"(koff) : "n"((IS_SG * G + g) * SLAB));
         // NT: the corpus is read once, by this CU only: non-temporal.  Several query groups share the tiles: keep
         // them in L2 for the siblings.
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(fill_rsrc, (lds_ptr_t)(fill_lds + g * SLABB + i * 1024), 16, c_off(i),
-                                                 fill_k0 + g * SLAB, 0, NT ? 2 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fill_rsrc, (lds_ptr_t)(stage_lds + g * SLABB + i * 1024), 16, c_off(i),
+                                                 koff, 0, NT ? 2 : 0);
     };
 
     // the ring is filled first: its HBM latency runs under the loading of Q below
     const bool any_tile = bx < p.n_tiles;
     if (any_tile)
-        for (int st = 0; st < NST; ++st) {
-            next_fill(st);
-            static_for<PPS>([&](auto pi_c) { issue_piece(pi_c); });
-        }
+        static_for<NST>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            next_fill(std::integral_constant<int, st % SPT>{}, st);
+            static_for<PPS>([&](auto pi_c) { issue_piece(std::integral_constant<int, st % SPT>{}, pi_c); });
+        });
+    // (the first stage of the main loop issues pieces 1.. of the last refill above once more -- same bytes to the same
+    // place, it keeps the vmcnt arithmetic uniform -- and piece 1 takes its K offset from piece 0)
+    asm volatile("s_movk_i32 %0, %1" : "=s"(koff) : "n"(((NST - 1) % SPT) * G * SLAB));
 
     // ---- the stationary operand: this wave's 64 queries, all of K, as B fragments ----------------------
     // 32x32x16: fragment s of a query = halfs 16 s + 8 (lane >> 5) ...; 16x16x32: halfs 32 s + 8 (lane >> 4) ...
@@ -352,11 +394,21 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
         auto lst_v = [&](int qb, int i) -> float & { return my_lists[(qb * 2 * K + i) * QS_QROWS]; };
         auto lst_r = [&](int qb, int i) -> int & { return *(int *)&my_lists[(qb * 2 * K + K + i) * QS_QROWS]; };
         constexpr int qb = decltype(qb_c)::value;
-        float mx = NEG_INF;
-        static_for<NGRP>([&](auto gi_c) {
-            mx = fmaxf(mx, fmaxf(fmaxf(score(qb_c, gi_c, 0), score(qb_c, gi_c, 1)),
-                                 fmaxf(score(qb_c, gi_c, 2), score(qb_c, gi_c, 3))));
-        });
+        // (the common case ends here: a wave alone on its SIMD pays every instruction of this test in matrix-pipe idle
+        // time -- v_max3 on the raw accumulators in one statement, not fmaxf, which quiets each MFMA result first: 9 instructions instead of 21)
+        auto max16 = [&](auto g0_c) -> float {   // groups g0 .. g0 + 3
+            constexpr int g0 = decltype(g0_c)::value;
+            using G0 = std::integral_constant<int, g0>;
+            using G1 = std::integral_constant<int, g0 + 1>;
+            using G2 = std::integral_constant<int, g0 + 2>;
+            using G3 = std::integral_constant<int, g0 + 3>;
+            return max16_raw(score(qb_c, G0{}, 0), score(qb_c, G0{}, 1), score(qb_c, G0{}, 2), score(qb_c, G0{}, 3),
+                             score(qb_c, G1{}, 0), score(qb_c, G1{}, 1), score(qb_c, G1{}, 2), score(qb_c, G1{}, 3),
+                             score(qb_c, G2{}, 0), score(qb_c, G2{}, 1), score(qb_c, G2{}, 2), score(qb_c, G2{}, 3),
+                             score(qb_c, G3{}, 0), score(qb_c, G3{}, 1), score(qb_c, G3{}, 2), score(qb_c, G3{}, 3));
+        };
+        float mx = max16(std::integral_constant<int, 0>{});
+        if constexpr (NGRP == 8) mx = fmaxf(mx, max16(std::integral_constant<int, 4>{}));
         float t = thr[qb];
         if (__builtin_amdgcn_ballot_w64(mx >= t) == 0ull) return;
         // Which of this lane's NE scores reach its threshold.  While the thresholds are cold almost every element has
@@ -525,6 +577,11 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
         }
         int cur_tile = bx;
         for (int ti = 0; (unsigned)cur_tile < (unsigned)p.n_tiles; ++ti) {
+            // (16x16x32) fragment addresses of the stage being read; made again here so that nothing more than the lane
+            // constant is live across the selection at the end of a tile
+            unsigned adr_lo = 0, adr_hi = 0;
+            if constexpr (MS == 16)
+                qsw_stage_addr(adr_lo, adr_hi, lane_off0, smem_base + (unsigned)(((ti * SPT) % NST) * STAGE));
             // ticket for the position LOOK tiles ahead: the atomic's return value is picked up at the end of this tile
             // (hipcc waits for it with a counted vmcnt: two dozen younger DMA pieces by then)
             // As asm, lane 0 only: hipcc would wait vmcnt(0) for a builtin atomic's result at once (it feeds a phi
@@ -569,20 +626,26 @@ __global__ __launch_bounds__(256, 1) void cosine_topk_walk_kernel(const KParams 
                     } else {
                         constexpr int ks = slab * 2 + (m >> 1), rp = m & 1;
                         constexpr int o0 = ng * SLABB + (nm & 1) * (32 * SLAB);
-                        qsw_stmt16<DT, (ks < QA_STEPS), ks == 0, (nm >> 1) * 64, o0, o0 + 16 * SLAB, FT>(
+                        if constexpr (last) qsw_stage_addr(adr_lo, adr_hi, lane_off0, st_nxt);
+                        qsw_stmt16<DT, (ks < QA_STEPS), ks == 0, o0, o0 + 16 * SLAB, FT>(
                             c16[rp * 8 + 0], c16[rp * 8 + 1], c16[rp * 8 + 2], c16[rp * 8 + 3], c16[rp * 8 + 4],
                             c16[rp * 8 + 5], c16[rp * 8 + 6], c16[rp * 8 + 7], x0, x1, qf[0][ks], qf[1][ks], qf[2][ks],
-                            qf[3][ks], y0, y1, lane_off0, st);
+                            qf[3][ks], y0, y1, (nm >> 1) ? adr_hi : adr_lo);
                     }
                     if constexpr (j == KSTG - 2) {
                         // every read of this stage is back: hand the ring over.  The stage just drained is
                         // refilled over the next KSTG statements (pieces after statements KSTG-1, 1, 3, ...)
                         wait_vmcnt<(NST - 2) * PPS>();
                         if (!(p.dbg & DBG_QS_NO_BARRIER)) __builtin_amdgcn_s_barrier();
-                        next_fill(it % NST);
+                        next_fill(std::integral_constant<int, (NST + sg) % SPT>{}, it % NST);
                     }
-                    if constexpr (j == KSTG - 1) issue_piece(std::integral_constant<int, 0>{});
-                    else if constexpr ((j & 1) == 1) issue_piece(std::integral_constant<int, (j + 1) / 2>{});
+                    // (the refill opened in this stage fetches K-slabs (NST + sg) % SPT of its tile; pieces 1.. of the
+                    // one opened a stage earlier are still going out)
+                    if constexpr (j == KSTG - 1)
+                        issue_piece(std::integral_constant<int, (NST + sg) % SPT>{}, std::integral_constant<int, 0>{});
+                    else if constexpr ((j & 1) == 1)
+                        issue_piece(std::integral_constant<int, (NST + sg + SPT - 1) % SPT>{},
+                                    std::integral_constant<int, (j + 1) / 2>{});
                 });
             });
             asm volatile("s_nop 15\n\ts_nop 7");  // last MFMA's D -> VALU readers

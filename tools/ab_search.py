@@ -41,7 +41,7 @@ for c_ in cands:
     walk = "old" not in c_ and "noqs" not in c_     # the walk kernel writes 32 words per workgroup, the others 8
     W = 32 if walk else 8
     ws[need:need + 256 * W * 8].zero_()
-    run(c_, iters=3); torch.cuda.synchronize()
+    run(c_, iters=int(os.environ.get('CLK_ITERS', '3'))); torch.cuda.synchronize()   # (CLK_ITERS=3000: stamps of a throttled launch)
     st = ws[need:need + 256 * W * 8].view(torch.int64).cpu().numpy().reshape(256, W).astype(np.float64)
     mhz = st[:, 0] / st[:, 1] * 100.0
     us = st[:, 1] / 100.0
