@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void mfma_peak16_kernel(const half8_t *__restr
 // Developer probe: cycles per v_mfma_f32_16x16x32_f16 in loops that add, one at a time, what the search walk's k-step has
 // around its MFMAs.  MODE 0: eight MFMAs per statement, A and B in arch VGPRs; 1: B in the accumulator file; 2: B rotating
 // over 16 fragments (64 registers) of the accumulator file; 3: (2) + the statement's v_xad and two ds_read_b128 of the
-// NEXT statement's A fragments; 4: (3) + the closing s_waitcnt lgkmcnt(0).  stamps[2 wg] = shader cycles (s_memtime),
+// NEXT statement's A fragments; 4: (3) + the closing s_waitcnt lgkmcnt(0); 5: (4) + one 1 KiB LDS-DMA piece after every
+// other statement (per-lane offsets, the walk's form), 6: the same piece without a per-lane offset (timing only),
+// 7: as 5 with the two pieces of an iteration back to back.  stamps[2 wg] = shader cycles (s_memtime),
 // stamps[2 wg + 1] = 100 MHz ticks (s_memrealtime) of wave 0's loop.
 #define MMRAG_PROBE_8(QC, Q0, Q1, Q2, Q3, PRE, POST)                                                                  \
     asm volatile(PRE "v_mfma_f32_16x16x32_f16 %[d0], %[a0], %[" Q0 "], %[d0]\n\t"                                     \
@@ -117,6 +119,24 @@ __global__ __launch_bounds__(256) void mfma_peak16_kernel(const half8_t *__restr
                      "v_mfma_f32_16x16x32_f16 %[d5], %[a1], %[" Q1 "], %[d5]\n\t"                                     \
                      "v_mfma_f32_16x16x32_f16 %[d6], %[a1], %[" Q2 "], %[d6]\n\t"                                     \
                      "v_mfma_f32_16x16x32_f16 %[d7], %[a1], %[" Q3 "], %[d7]" POST                                    \
+                 : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [d4] "+v"(d4), [d5] "+v"(d5),           \
+                   [d6] "+v"(d6), [d7] "+v"(d7), [n0] "=&v"(n0), [n1] "=&v"(n1), [t] "=&v"(tmp)                        \
+                 : [a0] "v"(a0), [a1] "v"(a1), [q0] QC(q0), [q1] QC(q1), [q2] QC(q2), [q3] QC(q3), [lo] "v"(lo),       \
+                   [st] "s"(st))
+// mode 8: the statement of mode 4 with its fillers spread over the MFMA gaps (one per gap) instead of bunched in front
+#define MMRAG_PROBE_8I(QC)                                                                                            \
+    asm volatile("v_mfma_f32_16x16x32_f16 %[d0], %[a0], %[q0], %[d0]\n\t"                                             \
+                 "v_xad_u32 %[t], %[lo], 64, %[st]\n\t"                                                               \
+                 "v_mfma_f32_16x16x32_f16 %[d1], %[a0], %[q1], %[d1]\n\t"                                             \
+                 "ds_read_b128 %[n0], %[t]\n\t"                                                                       \
+                 "v_mfma_f32_16x16x32_f16 %[d2], %[a0], %[q2], %[d2]\n\t"                                             \
+                 "ds_read_b128 %[n1], %[t] offset:2048\n\t"                                                           \
+                 "v_mfma_f32_16x16x32_f16 %[d3], %[a0], %[q3], %[d3]\n\t"                                             \
+                 "v_mfma_f32_16x16x32_f16 %[d4], %[a1], %[q0], %[d4]\n\t"                                             \
+                 "v_mfma_f32_16x16x32_f16 %[d5], %[a1], %[q1], %[d5]\n\t"                                             \
+                 "v_mfma_f32_16x16x32_f16 %[d6], %[a1], %[q2], %[d6]\n\t"                                             \
+                 "v_mfma_f32_16x16x32_f16 %[d7], %[a1], %[q3], %[d7]\n\t"                                             \
+                 "s_waitcnt lgkmcnt(0)"                                                                               \
                  : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [d4] "+v"(d4), [d5] "+v"(d5),           \
                    [d6] "+v"(d6), [d7] "+v"(d7), [n0] "=&v"(n0), [n1] "=&v"(n1), [t] "=&v"(tmp)                        \
                  : [a0] "v"(a0), [a1] "v"(a1), [q0] QC(q0), [q1] QC(q1), [q2] QC(q2), [q3] QC(q3), [lo] "v"(lo),       \
@@ -132,7 +152,8 @@ __device__ __forceinline__ void probe_stmt(f32x4_t &d0, f32x4_t &d1, f32x4_t &d2
     else if constexpr (MODE == 3)
         MMRAG_PROBE_8("a", "q0", "q1", "q2", "q3",
                       "v_xad_u32 %[t], %[lo], 64, %[st]\n\tds_read_b128 %[n0], %[t]\n\tds_read_b128 %[n1], %[t] offset:2048\n\t", "");
-    else
+    else if constexpr (MODE == 8) MMRAG_PROBE_8I("a");
+    else   // 4 and the LDS-DMA modes
         MMRAG_PROBE_8("a", "q0", "q1", "q2", "q3",
                       "v_xad_u32 %[t], %[lo], 64, %[st]\n\tds_read_b128 %[n0], %[t]\n\tds_read_b128 %[n1], %[t] offset:2048\n\t",
                       "\n\ts_waitcnt lgkmcnt(0)");
@@ -154,15 +175,29 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const half8_t *__res
 #pragma unroll
     for (int j = 0; j < 16; ++j) c[j] = f32x4_t{};
     const unsigned lo = (unsigned)(size_t)(__attribute__((address_space(3))) void *)tile + lane * 16;
+    // (LDS-DMA modes) pieces land in the upper half of `tile`, which the statements do not read; source: the seed (L2)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)seed, 0, 4096, 0x00020000);
+    const unsigned voff = (unsigned)((lane >> 3) * 128 + ((lane & 7) ^ (lane >> 4)) * 16);
+    auto piece = [&](int it, int h) {
+        typedef __attribute__((address_space(3))) void *lds_t;
+        char *dst = (char *)tile + 32768 + (threadIdx.x >> 6) * 8192 + (((it << 1) + h) & 7) * 1024;
+        if constexpr (MODE == 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t)dst, 16, 0, (h + (it & 1) * 2) * 1024, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t)dst, 16, voff, (h + (it & 1) * 2) * 1024, 0, 2);
+    };
     const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         const unsigned st = (unsigned)((it & 7) * 4096);
         constexpr int R = MODE >= 2 ? 4 : 0;   // B fragments rotate over q[0..15] / stay q[0..3]
         probe_stmt<MODE>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], a0, a1, q[0], q[1], q[2], q[3], b0, b1, lo, st);
         probe_stmt<MODE>(c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], b0, b1, q[R], q[R + 1], q[R + 2], q[R + 3], a0, a1, lo, st + 1024);
+        if constexpr (MODE == 5 || MODE == 6) piece(it, 0);
         probe_stmt<MODE>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], a0, a1, q[2 * R], q[2 * R + 1], q[2 * R + 2], q[2 * R + 3], b0, b1, lo, st + 2048);
         probe_stmt<MODE>(c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], b0, b1, q[3 * R], q[3 * R + 1], q[3 * R + 2], q[3 * R + 3], a0, a1, lo, st + 3072);
+        if constexpr (MODE >= 5 && MODE <= 7) piece(it, 1);
+        if constexpr (MODE == 7) piece(it, 0);
+        if constexpr (MODE >= 5 && MODE <= 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
+    if constexpr (MODE >= 5 && MODE <= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_nop 15\n\ts_nop 7");
     f32x4_t t = c[0];
@@ -236,7 +271,7 @@ int mmrag_bench_mfma_f16(const void *seed, float *out, int iters, int64_t *flops
 
 // developer probe (tools/mfma_probe.py): 32 MFMAs per iteration and wave; not part of the reference-facing surface
 int mmrag_internal_mfma_probe(const void *seed, float *out, int iters, int mode, long long *stamps, void *stream) {
-    MMRAG_CHECK_ARG(seed && out && iters > 0 && mode >= 0 && mode <= 4, "mfma_probe: bad arguments");
+    MMRAG_CHECK_ARG(seed && out && iters > 0 && mode >= 0 && mode <= 8, "mfma_probe: bad arguments");
     const int grid = num_cus();
     hipStream_t s = (hipStream_t)stream;
     switch (mode) {
@@ -244,7 +279,11 @@ int mmrag_internal_mfma_probe(const void *seed, float *out, int iters, int mode,
     case 1: mfma_probe_kernel<1><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
     case 2: mfma_probe_kernel<2><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
     case 3: mfma_probe_kernel<3><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
-    default: mfma_probe_kernel<4><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 4: mfma_probe_kernel<4><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 5: mfma_probe_kernel<5><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 6: mfma_probe_kernel<6><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 7: mfma_probe_kernel<7><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    default: mfma_probe_kernel<8><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
     }
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;
