@@ -354,6 +354,23 @@ def test_walk_kernel_masks_offsets_and_exact_ties(N):
         assert np.array_equal(s, es) and np.array_equal(r, er)
 
 
+def test_walk_kernel_ticketed_tail_is_complete_on_short_rows(N):
+    """384-d rows make a tile only a dozen ring pieces: the ticket of a tail tile has to be waited for explicitly (the
+    ring's hand-over waits do not cover it) -- without that wait one launch in a few lost a whole tail tile.  Integer
+    data (exact scores, ties everywhere), the oracle once, then the same answer from every one of a dozen launches."""
+    n, d, B = 400_003, 384, 256   # 24.4 tiles per workgroup: the last three positions are handed out by ticket
+    g = np.random.default_rng(91)
+    ci = g.integers(-2, 3, size=(n, d)).astype(np.float32)
+    qi = g.integers(-2, 3, size=(B, d)).astype(np.float32)
+    s, r, es, er = run(N, qi, ci, 5, torch.float16, dbg=N.DBG_FORCE_QS)
+    assert np.array_equal(s, es) and np.array_equal(r, er)
+    qd, _ = to_dev(N, qi, torch.float16)
+    cd, _ = to_dev(N, ci, torch.float16)
+    for launch in range(12):
+        s2, r2 = N.cosine_topk(qd, cd, n, d, 5, dbg=N.DBG_FORCE_QS)
+        assert np.array_equal(r2.cpu().numpy(), r) and np.array_equal(s2.cpu().numpy(), s), launch
+
+
 # ---- fp32 storage, more than 64 queries: scores come from a 3-term bf16 split (csrc/search.hip); the bound is the
 # north star's 1e-4, tested on the reference's own vectors and on random data; integer data stays bit-exact
 def test_fp32_split_on_the_wal70_vectors(N, wal70):
