@@ -547,11 +547,14 @@ Plan make_plan(int B, long long n, int k, unsigned dbg = 0) {
     if (want_pre && !(dbg & DBG_NO_PREPASS)) pl.pre_tiles = cus;
     pl.n_lists = pl.grid_x + (want_pre ? 1 : 0);  // one merged list per workgroup per query (+ the sample's)
     pl.b_pad = pl.grid_y * qrows;
-    // query-stationary kernel: more than 128 queries and a long shard.  It needs >= 256 rows per walker to run at
-    // all (qs_room); it pays from about 6 tiles of 256 rows per CU (profiles/r02_config_sweep.txt: 1M rows 424 vs
-    // 463 us, 500k 248 vs 258, 250k 164 vs 159, 125k 178 vs 99 -- its launches have ~35 us of fixed cost each).
+    // query-stationary kernels: more than 128 queries and a long shard.  They need >= 256 rows per walker to run at
+    // all (qs_room).  The single-launch walk (list depth 5) pays from 3.75 tiles of 256 rows per CU
+    // (profiles/r03_config_sweep.txt, walk vs slab-ring: 1M rows 379 vs 467 us, 500k 224 vs 258, 250k 154 vs 158,
+    // 125k 112 vs 99); the three-launch plan (depth 10) from about 6 (profiles/r02_config_sweep.txt: its launches have
+    // ~35 us of fixed cost each).
     pl.qs_room = pl.WN == 8 && pl.n_tiles >= cus;
-    pl.qs_ok = pl.qs_room && !(dbg & DBG_NO_QS) && (pl.n_tiles >= 6 * cus || (dbg & DBG_FORCE_QS));
+    const bool long_enough = pl.K <= 5 ? pl.n_tiles * 4 >= 15 * cus : pl.n_tiles >= 6 * cus;
+    pl.qs_ok = pl.qs_room && !(dbg & DBG_NO_QS) && (long_enough || (dbg & DBG_FORCE_QS));
     return pl;
 }
 

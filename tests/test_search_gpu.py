@@ -232,7 +232,7 @@ def test_randomised_shapes_against_oracle(N):
 
 
 # ---- query-stationary kernel (csrc/search_qs.hip): more than 128 queries, fp16/bf16 rows of 768 / 1024 / 1536 bytes.
-# The product sends shards of >= 6 x 256 rows per CU there; DBG_FORCE_QS makes it take the small shards of these tests
+# The product sends shards of >= 6 x 256 rows per CU there (3.75 x 256 for the single-launch walk at list depth 5); DBG_FORCE_QS makes it take the small shards of these tests
 # (>= 256 rows per CU).  Every case is also run through the slab-ring kernel (DBG_NO_QS): bit-for-bit agreement.
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,n,d", [
