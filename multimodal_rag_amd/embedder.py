@@ -282,7 +282,8 @@ class EmbeddingManager:
                 for at, row in zip(todo, dev.cpu().numpy()):
                     self.cache.put(keys[at], row)
             self._stack([], len(todo))
-            return self._split(res, len(texts))
+            with tracing.stage("split"):
+                return self._split(res, len(texts))
         if todo:
             self._encode_into(texts, rows, todo, keys)
         matrix = self._stack(rows, len(todo))

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import _native
+from .tracing import stage
 
 logger = logging.getLogger(__name__)
 
@@ -208,11 +209,24 @@ class DeviceEncoder:
             L = min(self.cfg.max_seq_length, self.cfg.max_pos)
             return self.encode_one(list(sequences[0])[:L])
         ids, pos, cu, max_len = self.pack(sequences)
-        d = self.device
-        ids_t = torch.from_numpy(ids).to(d, non_blocking=True)
-        pos_t = torch.from_numpy(pos).to(d, non_blocking=True)
-        cu_t = torch.from_numpy(cu).to(d, non_blocking=True)
-        return self.forward_packed(ids_t, pos_t, cu_t, max_len)
+        return self.forward_packed(*self._upload(ids, pos, cu), max_len)
+
+    def _upload(self, ids: np.ndarray, pos: np.ndarray, cu: np.ndarray):
+        """token ids, positions and sequence starts -> the device in ONE copy from pinned memory.  A copy from
+        pageable memory is not asynchronous: the call returns only when everything enqueued on the stream before it
+        has run, so a second caller's upload waited for the first caller's whole forward + search (concurrent
+        batch_query callers ran no faster than one: tools/served_callers.py).  torch's caching host allocator hands
+        the pinned block back only after the copy has run."""
+        n, b = ids.size, cu.size
+        n4 = (n + 3) & ~3                                   # 16-byte aligned segments
+        host = torch.empty(2 * n4 + b, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else \
+            torch.empty(2 * n4 + b, dtype=torch.int32)
+        h = host.numpy()
+        h[:n] = ids
+        h[n4:n4 + n] = pos
+        h[2 * n4:] = cu
+        dev = host.to(self.device, non_blocking=True)
+        return dev[:n], dev[n4:n4 + n], dev[2 * n4:]
 
     def encode_id_rows(self, ids2d: np.ndarray, lens: np.ndarray) -> torch.Tensor:
         """Array form of `encode_ids` (what the native tokenizer returns): row i of `ids2d` [B, W] int32 holds
@@ -229,10 +243,9 @@ class DeviceEncoder:
         pos = np.broadcast_to(np.arange(W, dtype=np.int32)[None, :], ids2d.shape)[keep]
         cu = np.zeros(len(lens) + 1, dtype=np.int32)
         np.cumsum(lens, out=cu[1:])
-        d = self.device
-        return self.forward_packed(torch.from_numpy(ids).to(d, non_blocking=True),
-                                   torch.from_numpy(np.ascontiguousarray(pos)).to(d, non_blocking=True),
-                                   torch.from_numpy(cu).to(d, non_blocking=True), int(lens.max()))
+        with stage("encode.upload"):
+            dev = self._upload(ids, pos, cu)
+        return self.forward_packed(*dev, int(lens.max()))
 
     # ---- one sequence of at most 64 tokens (the online /query shape): the forward is a chain of ~33 kernels of 3-5 us and
     # the HOST's launch calls (4 us each) are what paces it.  The chain is captured once per token count into a HIP graph;
@@ -288,11 +301,16 @@ class DeviceEncoder:
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         T, B = ids.numel(), cu_seqlens.numel() - 1
         need = _native.encoder_workspace_bytes(self.desc, T, B, self._f32)
-        with self._launch_lock:
-            if self._workspace is None or self._workspace.numel() < need:
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-            return _native.encoder_forward(self.desc, self._ptrs, ids, pos_ids, cu_seqlens, max_len,
-                                           workspace=self._workspace, out=out, f32=self._f32)
+        with stage("encode.lock"):
+            self._launch_lock.acquire()
+        try:
+            with stage("encode.launch"):
+                if self._workspace is None or self._workspace.numel() < need:
+                    self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+                return _native.encoder_forward(self.desc, self._ptrs, ids, pos_ids, cu_seqlens, max_len,
+                                               workspace=self._workspace, out=out, f32=self._f32)
+        finally:
+            self._launch_lock.release()
 
     @property
     def dim(self) -> int:

@@ -423,13 +423,21 @@ class VectorIndex:
 
     def _collect(self, scores, rows, include, ids_t, docs_t, metas_t, emb_src) -> Dict[str, Any]:
         # one device -> host copy each, then plain Python lists: per-element numpy scalars cost 10x a list item
-        if rows.is_cuda and rows._base is not None and scores._base is not None and rows._base.data_ptr() == scores._base.data_ptr():
-            host = rows._base.cpu()               # packed [rows | scores] (cosine_topk(packed_out=True)): ONE copy, one wait
-            nb = rows.numel()
-            rows_h = host[: nb * 8].view(torch.int64).view(rows.shape)
-            scores_h = host[nb * 8:].view(torch.float32).view(scores.shape)
-        else:
-            rows_h, scores_h = rows.cpu(), scores.cpu()
+        with stage("collect.wait"):               # (the device's share of the call: encoder + search finish here)
+            if rows.is_cuda and rows._base is not None and scores._base is not None and rows._base.data_ptr() == scores._base.data_ptr():
+                # packed [rows | scores] (cosine_topk(packed_out=True)): ONE copy into pinned memory and a wait for
+                # ITS event -- a blocking copy to pageable memory (`.cpu()`) holds the stream inside the runtime
+                # until it is through, and other callers' launches queue up behind it
+                host = torch.empty(rows._base.shape, dtype=rows._base.dtype).pin_memory()
+                host.copy_(rows._base, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                done.synchronize()
+                nb = rows.numel()
+                rows_h = host[: nb * 8].view(torch.int64).view(rows.shape)
+                scores_h = host[nb * 8:].view(torch.float32).view(scores.shape)
+            else:
+                rows_h, scores_h = rows.cpu(), scores.cpu()
         rows_l = rows_h.tolist()
         dist_l = (1.0 - scores_h).tolist() if "distances" in include else None        # float32 arithmetic, as before
         want_m, want_d, want_e = "metadatas" in include, "documents" in include, "embeddings" in include

@@ -22,6 +22,7 @@ import time
 from typing import Dict
 
 _lock = threading.Lock()
+timeline = None   # developer hook: a list collects (thread, stage, start, end) of every stage (tools/served_callers.py)
 _stages: Dict[str, list] = {}      # name -> [calls, total seconds, max seconds]
 _roctx = None
 _roctx_tried = False
@@ -65,6 +66,8 @@ def stage(name: str):
         dt = time.perf_counter() - t0
         if lib is not None:
             lib.roctxRangePop()
+        if timeline is not None:
+            timeline.append((threading.get_ident(), name, t0, t0 + dt))
         with _lock:
             rec = _stages.get(name)
             if rec is None:
