@@ -332,6 +332,12 @@ int mmrag_wordpiece_encode_batch(const void *tk, const uint32_t *cps, const int6
     const Vocab &v = *(const Vocab *)tk;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n) n_threads = n > 0 ? n : 1;
+    // a thread is worth starting for ~16 k code points (a 256-query batch of one-line queries is faster on ONE thread:
+    // 0.28 ms against 0.53 ms on eight, all of the difference thread start-up)
+    if (n > 0) {
+        const int64_t by_work = 1 + (offsets[n] - offsets[0]) / 16384;
+        if (n_threads > by_work) n_threads = (int)by_work;
+    }
     auto work = [&](int lo, int hi) {
         for (int i = lo; i < hi; ++i)
             encode_one(v, cps + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), max_length,

@@ -265,7 +265,8 @@ class EmbeddingManager:
     @staticmethod
     def _split(res: Dict[str, Any], n: int) -> List[Dict[str, Any]]:
         """collection.query's lists of lists -> one dict per query (embedder.py:604-609)"""
-        return [{key: (res[key][b] if res.get(key) else []) for key in RESULT_KEYS} for b in range(n)]
+        cols = [res[key] if res.get(key) else [[] for _ in range(n)] for key in RESULT_KEYS]
+        return [dict(zip(RESULT_KEYS, per_query)) for per_query in zip(*(col[:n] for col in cols))]
 
     def _answer(self, texts: Sequence[str], n_results: int, filter_dict: Optional[Dict]) -> List[Dict[str, Any]]:
         """Blocking, runs in ONE worker thread: cache lookups, ONE encoder pass for the misses, ONE collection.query

@@ -446,8 +446,12 @@ class VectorIndex:
                                "embeddings": [] if want_e else None}
         # every table is read with ONE itemgetter call over all hits of the batch (a C loop), then cut per query:
         # B x k Python-level index operations and dict() calls were most of the host time of a 256-query batch
-        counts = [k_ if row[-1] >= 0 else sum(1 for r in row if r >= 0) for row in rows_l for k_ in (len(row),)]
-        flat = [r for row, c in zip(rows_l, counts) for r in row[:c]]            # misses (-1) only trail
+        if rows_h.numel() and int(rows_h.min()) >= 0:                            # no misses at all (the usual batch)
+            counts = None
+            flat = rows_h.reshape(-1).tolist()
+        else:
+            counts = [k_ if row[-1] >= 0 else sum(1 for r in row if r >= 0) for row in rows_l for k_ in (len(row),)]
+            flat = [r for row, c in zip(rows_l, counts) for r in row[:c]]        # misses (-1) only trail
         if len(flat) == 1:
             pick = lambda table: (table[flat[0]],)                               # noqa: E731  (itemgetter(x) alone returns the item)
         elif flat:
@@ -458,6 +462,19 @@ class VectorIndex:
         ids_f = pick(ids_t)
         metas_f = list(map(dict, pick(metas_t))) if want_m else None
         docs_f = pick(docs_t) if want_d else None
+        if counts is None:
+            # the common case, every query has all its k hits: cut the flat columns with one comprehension each
+            k_, nf = len(rows_l[0]), len(flat)
+            out["ids"] = [list(ids_f[lo:lo + k_]) for lo in range(0, nf, k_)]
+            if dist_l is not None:
+                out["distances"] = dist_l
+            if want_m:
+                out["metadatas"] = [metas_f[lo:lo + k_] for lo in range(0, nf, k_)]
+            if want_d:
+                out["documents"] = [list(docs_f[lo:lo + k_]) for lo in range(0, nf, k_)]
+            if want_e:
+                out["embeddings"] = [self._fetch(flat[lo:lo + k_], emb_src) for lo in range(0, nf, k_)]
+            return out
         lo = 0
         for b, c in enumerate(counts):
             hi = lo + c
