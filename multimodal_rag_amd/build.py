@@ -73,7 +73,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+    build_hostrows(force, run)
     return LIB
+
+
+def build_hostrows(force: bool, run) -> str:
+    """the CPython extension that builds a batch's result lists in C (csrc/hostrows.c; host only, plain C)"""
+    import sysconfig
+
+    src = os.path.join(CSRC, "hostrows.c")
+    out = os.path.join(LIBDIR, "_hostrows" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        cc = shutil.which("gcc") or shutil.which("cc") or "gcc"
+        run([cc, "-O2", "-shared", "-fPIC", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", out])
+    return out
 
 
 if __name__ == "__main__":

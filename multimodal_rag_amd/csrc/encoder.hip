@@ -20,6 +20,8 @@
 #include "mmrag_internal.h"
 #include "tile_dma.h"
 
+#include <atomic>
+#include <chrono>
 #include <type_traits>
 
 #include <limits.h>
@@ -1481,6 +1483,8 @@ int launch_linear(const void *x, int M, int K, const void *wt, int N, const floa
 }  // namespace mmrag_impl
 using namespace mmrag_impl;
 
+static std::atomic<long long> g_last_forward_us{0};
+
 extern "C" {
 
 int mmrag_linear_f16(const void *x, int64_t M, int K, const void *wt, int N, const float *bias, int act,
@@ -1709,6 +1713,8 @@ static int check_desc(const mmrag_encoder_desc *d) {
     return MMRAG_OK;
 }
 
+long long mmrag_internal_last_forward_us(void) { return g_last_forward_us.load(std::memory_order_relaxed); }
+
 int mmrag_encoder_forward(const mmrag_encoder_desc *d, const void *const *w, const int32_t *ids,
                           const int32_t *pos_ids, const int32_t *cu_seqlens, const int32_t *sel, int64_t T, int B,
                           int max_len, float *out, void *workspace, size_t workspace_bytes, void *stream) {
@@ -1719,9 +1725,14 @@ int mmrag_encoder_forward(const mmrag_encoder_desc *d, const void *const *w, con
     MMRAG_CHECK_ARG(d->pool != 2 || sel, "encoder_forward: MMRAG_POOL_SELECT needs sel");
     EncBuffers b;
     RUN(carve(d, T, B, workspace, workspace_bytes, &b));
+    const auto t0 = std::chrono::steady_clock::now();
     RUN(mmrag_embed_ln_f16(ids, pos_ids, w[0], w[1], w[2], (const float *)w[3], (const float *)w[4], b.x, T,
                            d->hidden, d->vocab, d->max_pos, d->ln_eps, stream));
-    return encoder_body(d, w + 5, b, cu_seqlens, sel, T, B, max_len, out, stream);
+    st = encoder_body(d, w + 5, b, cu_seqlens, sel, T, B, max_len, out, stream);
+    // (developer read-out: how long the launches of the last forward took inside the library, as opposed to around it)
+    g_last_forward_us.store((long long)std::chrono::duration_cast<std::chrono::microseconds>(
+                                std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    return st;
 }
 
 int mmrag_vit_forward(const mmrag_encoder_desc *d, const void *const *w, const void *pixels, int pixel_kind,

@@ -30,12 +30,13 @@ import numpy as np
 from . import tracing
 from .config import settings
 from .engines import CLIP_MODEL_NAMES, ClipEngine, HipEngine, _is_clip_dir, load_item_image  # noqa: F401 (re-exported)
-from .hostutil import CountingLRU, call_with_retry
+from .hostutil import CountingLRU, call_with_retry, load_hostrows
 
 logger = logging.getLogger(__name__)
 
 ITEM_KINDS = ("text", "table", "image")           # the kinds embed_and_store counts (embedder.py:477-479)
 RESULT_KEYS = ("ids", "distances", "metadatas", "documents")
+_HOSTROWS = load_hostrows()
 _COLLECTION_NOTE = {"description": "Multi-modal RAG embeddings"}
 
 
@@ -266,6 +267,8 @@ class EmbeddingManager:
     def _split(res: Dict[str, Any], n: int) -> List[Dict[str, Any]]:
         """collection.query's lists of lists -> one dict per query (embedder.py:604-609)"""
         cols = [res[key] if res.get(key) else [[] for _ in range(n)] for key in RESULT_KEYS]
+        if _HOSTROWS is not None and all(type(col) is list and len(col) == n for col in cols):
+            return _HOSTROWS.split(RESULT_KEYS, tuple(cols))
         return [dict(zip(RESULT_KEYS, per_query)) for per_query in zip(*(col[:n] for col in cols))]
 
     def _answer(self, texts: Sequence[str], n_results: int, filter_dict: Optional[Dict]) -> List[Dict[str, Any]]:

@@ -64,3 +64,23 @@ async def call_with_retry(what: str, fn: Callable[..., Any], *args: Any, attempt
                 raise
             log.warning("%s: attempt %d failed (%s); retrying in %d s", what, n + 1, e, 2 ** n)
             await sleep(2 ** n)
+
+
+def load_hostrows():
+    """the C extension that builds a batch's result lists (csrc/hostrows.c, built by `python -m multimodal_rag_amd.build`),
+    or None when it has not been built: the callers keep their plain-Python form of the same loops"""
+    import importlib.util
+    import os
+    import sysconfig
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                        "_hostrows" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if os.environ.get("MMRAG_NO_HOSTROWS") or not os.path.exists(path):
+        return None
+    try:
+        spec = importlib.util.spec_from_file_location("_hostrows", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    except Exception:   # noqa: BLE001 -- an unloadable helper must not take the service down
+        return None

@@ -24,7 +24,10 @@ import numpy as np
 import torch
 
 from . import _native
+from .hostutil import load_hostrows
 from .tracing import stage
+
+_HOSTROWS = load_hostrows()
 
 logger = logging.getLogger(__name__)
 
@@ -438,7 +441,6 @@ class VectorIndex:
                 scores_h = host[nb * 8:].view(torch.float32).view(scores.shape)
             else:
                 rows_h, scores_h = rows.cpu(), scores.cpu()
-        rows_l = rows_h.tolist()
         dist_l = (1.0 - scores_h).tolist() if "distances" in include else None        # float32 arithmetic, as before
         want_m, want_d, want_e = "metadatas" in include, "documents" in include, "embeddings" in include
         out: Dict[str, Any] = {"ids": [], "distances": [] if dist_l is not None else None,
@@ -446,10 +448,21 @@ class VectorIndex:
                                "embeddings": [] if want_e else None}
         # every table is read with ONE itemgetter call over all hits of the batch (a C loop), then cut per query:
         # B x k Python-level index operations and dict() calls were most of the host time of a 256-query batch
-        if rows_h.numel() and int(rows_h.min()) >= 0:                            # no misses at all (the usual batch)
+        no_miss = bool(rows_h.numel()) and int(rows_h.min()) >= 0
+        if no_miss and _HOSTROWS is not None and not want_e:
+            # every query has all its k hits: one pass in C over the row numbers (csrc/hostrows.c) -- the same objects
+            # in the same order as the comprehensions below, without the interpreter in the loop
+            ids_ll, docs_ll, metas_ll = _HOSTROWS.gather(rows_h.contiguous().numpy(), rows_h.shape[1], ids_t,
+                                                         docs_t if want_d else None, metas_t if want_m else None)
+            out["ids"], out["documents"], out["metadatas"] = ids_ll, docs_ll, metas_ll
+            if dist_l is not None:
+                out["distances"] = dist_l
+            return out
+        if no_miss:                                                              # no misses at all (the usual batch)
             counts = None
             flat = rows_h.reshape(-1).tolist()
         else:
+            rows_l = rows_h.tolist()
             counts = [k_ if row[-1] >= 0 else sum(1 for r in row if r >= 0) for row in rows_l for k_ in (len(row),)]
             flat = [r for row, c in zip(rows_l, counts) for r in row[:c]]        # misses (-1) only trail
         if len(flat) == 1:
@@ -464,7 +477,7 @@ class VectorIndex:
         docs_f = pick(docs_t) if want_d else None
         if counts is None:
             # the common case, every query has all its k hits: cut the flat columns with one comprehension each
-            k_, nf = len(rows_l[0]), len(flat)
+            k_, nf = rows_h.shape[1], len(flat)
             out["ids"] = [list(ids_f[lo:lo + k_]) for lo in range(0, nf, k_)]
             if dist_l is not None:
                 out["distances"] = dist_l

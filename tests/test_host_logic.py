@@ -378,3 +378,55 @@ def test_delete_between_search_launch_and_result_building_keeps_hits_whole():
     assert ids[1] not in ix.get(where={"doc_id": "doc_a"})["ids"]
     assert ix._rows_where({"$or": [{"doc_id": "doc_a"}, {"type": "text"}]}).tolist() == [0, 2, 3, 4, 5]   # scan fallback
     # (compact() moves rows with a HIP kernel: tests/test_pipeline_gpu.py covers it)
+
+
+def test_result_rows_built_in_c_equal_the_python_form():
+    """csrc/hostrows.c (CPython extension built by `python -m multimodal_rag_amd.build`): the per-query lists of a
+    batch's hits -- same objects, same order, metadata dicts copied -- and the per-query dicts, against the plain
+    Python loops they replace; rows outside the tables are an IndexError, not a read past the end"""
+    import numpy as np
+    import torch
+
+    import multimodal_rag_amd.embedder as E
+    import multimodal_rag_amd.index as I
+    from multimodal_rag_amd.hostutil import load_hostrows
+
+    H = load_hostrows()
+    assert H is not None, "lib/_hostrows*.so is missing: run python -m multimodal_rag_amd.build"
+    n, B, k = 5000, 37, 5
+    ids = [f"id{i}" for i in range(n)]
+    docs = [None if i % 3 else f"text {i}" for i in range(n)]
+    metas = [{"doc_id": f"d{i // 7}", "n": i} for i in range(n)]
+    g = np.random.default_rng(5)
+    rows = torch.from_numpy(g.integers(0, n, size=(B, k)).astype(np.int64))
+    scores = torch.from_numpy(g.random((B, k)).astype(np.float32))
+    idx = I.VectorIndex.__new__(I.VectorIndex)
+    inc = ["metadatas", "documents", "distances"]
+
+    def both(r, include):
+        saved = I._HOSTROWS, E._HOSTROWS
+        try:
+            I._HOSTROWS = E._HOSTROWS = H
+            c = E.EmbeddingManager._split(idx._collect(scores, r, include, ids, docs, metas, None), B)
+            I._HOSTROWS = E._HOSTROWS = None
+            p = E.EmbeddingManager._split(idx._collect(scores, r, include, ids, docs, metas, None), B)
+        finally:
+            I._HOSTROWS, E._HOSTROWS = saved
+        return c, p
+
+    c, p = both(rows, inc)
+    assert c == p and len(c) == B and c[0]["ids"] == [ids[int(r)] for r in rows[0]]
+    assert c[3]["metadatas"][1] == metas[int(rows[3, 1])] and c[3]["metadatas"][1] is not metas[int(rows[3, 1])]
+    assert c[3]["documents"][2] is docs[int(rows[3, 2])]
+    c, p = both(rows, ["distances"])                       # columns not asked for
+    assert c == p and c[0]["metadatas"] == [] and c[0]["documents"] == []
+    miss = rows.clone()
+    miss[4, 2:] = -1
+    miss[9, :] = -1
+    c, p = both(miss, inc)                                 # misses take the Python form either way
+    assert c == p and len(c[4]["ids"]) == 2 and c[9]["ids"] == []
+    with pytest.raises(IndexError):
+        H.gather(np.array([[0, n]], dtype=np.int64), 2, ids, docs, metas)
+    with pytest.raises(ValueError):
+        H.gather(np.zeros(7, dtype=np.int64), 2, ids, None, None)
+    assert H.split(("a", "b"), ([1, 2], [[3], [4]])) == [{"a": 1, "b": [3]}, {"a": 2, "b": [4]}]

@@ -19,6 +19,14 @@ eng = HipEngine("BAAI/bge-base-en-v1.5", "cuda:0")
 vocab, words = synthetic_vocab(eng.encoder.cfg.vocab)
 eng.tokenizer = NativeWordPieceTokenizer(vocab)
 m = EmbeddingManager(engine=eng, enable_cache=False)
+import ctypes
+from multimodal_rag_amd import _native, encoder as _enc
+_L = _native.lib(); _L.mmrag_internal_last_forward_us.restype = ctypes.c_longlong
+_inside = []
+_orig = _native.encoder_forward
+def _timed(*a, **k):
+    r = _orig(*a, **k); _inside.append(_L.mmrag_internal_last_forward_us()); return r
+_native.encoder_forward = _timed
 async def go():
     await m.initialize()
     ids = [f"doc_{i // 64:012x}_text_{i % 64}" for i in range(n_rows)]
@@ -27,7 +35,7 @@ async def go():
     texts = [" ".join(words[(i * 7 + j * 131) % len(words)] for j in range(7)) + f" {i % 97}" for i in range(4096)]
     await m.batch_query(texts[:256], n_results=5)
     for callers in (1, 2, 3, 4):
-        tracing.reset()
+        tracing.reset(); _inside.clear()
         tracing.timeline = None
         t_end, t0 = time.perf_counter() + 2.0, time.perf_counter()
         done = [0]
@@ -40,7 +48,7 @@ async def go():
         await asyncio.gather(*[caller(j) for j in range(callers)])
         dt = time.perf_counter() - t0
         st = {k: v["mean_ms"] for k, v in tracing.snapshot().items()}
-        print(f"{callers} callers: {done[0] / dt:9.0f} queries/s   stages (mean ms): {st}", flush=True)
+        print(f"{callers} callers: {done[0] / dt:9.0f} queries/s   launches inside the library: mean {sum(_inside) / max(1, len(_inside)) / 1e3:.3f} ms   stages (mean ms): {st}", flush=True)
         if tracing.timeline:
             tl = sorted(tracing.timeline, key=lambda e: e[2]); base = tl[len(tl) // 2][2]; tids = {}
             for tid, name, a, b in tl[len(tl) // 2: len(tl) // 2 + 60]:
