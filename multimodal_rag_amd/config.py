@@ -47,6 +47,12 @@ class Settings:
     # requests the dispatcher batched it with).  "true" keeps the exact float32 matrix instruction for every batch
     # size (the batch is scanned 64 queries at a time: identical scores whatever the batch, ~2.5x the scan time)
     MMRAG_F32_EXACT_SEARCH: bool = field(default_factory=lambda: _b("MMRAG_F32_EXACT_SEARCH", "false"))
+    # Row tables (ids, documents, metadata dicts) are millions of long-lived Python objects; every older-generation pass
+    # of the cyclic collector walks them, and the lists a query batch builds trigger such passes: half of the 1 ms a
+    # 256-query answer takes to build.  After this many rows have been added since the last time, the index calls
+    # gc.freeze(): everything alive moves to the permanent generation (still freed by reference counting; no longer
+    # scanned for cycles).  0 turns it off.
+    MMRAG_GC_FREEZE_ROWS: int = field(default_factory=lambda: int(os.getenv("MMRAG_GC_FREEZE_ROWS", "100000")))
     MMRAG_WEIGHT_SEED: int = field(default_factory=lambda: int(os.getenv("MMRAG_WEIGHT_SEED", "0")))
     # "fp16" (throughput path) or "fp32": the reference's own arithmetic (SentenceTransformer.encode is float32,
     # embedder.py:397-403) -- scores within 1e-4 of the float32 model; pair it with MMRAG_INDEX_DTYPE=float32

@@ -15,6 +15,7 @@ No vector arithmetic happens in this file: torch provides device buffers and cop
 """
 from __future__ import annotations
 
+import gc
 import logging
 import operator
 import threading
@@ -315,6 +316,7 @@ class VectorIndex:
             self._meta_index.append([metadatas[i] for i in keep])
             self._set_alive(self._n, self._n + len(keep))
             self._n += len(keep)
+            self._grown(len(keep))
 
     def add_rows_device(self, rows_packed: torch.Tensor, documents, metadatas, ids):
         """Append rows that are already in storage layout [m, ld] (bulk loads, benchmarks)."""
@@ -330,6 +332,17 @@ class VectorIndex:
             self._meta_index.append(self._metadatas[self._n: self._n + m])
             self._set_alive(self._n, self._n + m)
             self._n += m
+            self._grown(m)
+
+    def _grown(self, m: int):
+        """row tables grew by m (caller holds the lock): see config.MMRAG_GC_FREEZE_ROWS"""
+        self._unfrozen_rows = getattr(self, "_unfrozen_rows", 0) + m
+        from .config import settings
+
+        every = settings.MMRAG_GC_FREEZE_ROWS
+        if every > 0 and self._unfrozen_rows >= every:
+            gc.freeze()
+            self._unfrozen_rows = 0
 
     def _is_dead(self, rows: np.ndarray) -> np.ndarray:
         return ((self._alive_host[rows >> 5] >> (rows & 31).astype(np.uint32)) & 1) == 0

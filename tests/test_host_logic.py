@@ -430,3 +430,27 @@ def test_result_rows_built_in_c_equal_the_python_form():
     with pytest.raises(ValueError):
         H.gather(np.zeros(7, dtype=np.int64), 2, ids, None, None)
     assert H.split(("a", "b"), ([1, 2], [[3], [4]])) == [{"a": 1, "b": [3]}, {"a": 2, "b": [4]}]
+
+
+def test_row_tables_leave_the_cyclic_collector_after_bulk_growth(monkeypatch):
+    """config.MMRAG_GC_FREEZE_ROWS: once that many rows have been added, everything alive is frozen out of the cyclic
+    collector's generations (gc.freeze); 0 turns the policy off"""
+    import gc
+
+    import multimodal_rag_amd.index as I
+    from multimodal_rag_amd.config import settings
+
+    idx = I.VectorIndex.__new__(I.VectorIndex)
+    try:
+        gc.unfreeze()
+        monkeypatch.setattr(settings, "MMRAG_GC_FREEZE_ROWS", 1000)
+        idx._grown(999)
+        assert gc.get_freeze_count() == 0
+        idx._grown(1)
+        assert gc.get_freeze_count() > 0 and idx._unfrozen_rows == 0
+        gc.unfreeze()
+        monkeypatch.setattr(settings, "MMRAG_GC_FREEZE_ROWS", 0)
+        idx._grown(10 ** 7)
+        assert gc.get_freeze_count() == 0
+    finally:
+        gc.unfreeze()
