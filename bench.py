@@ -400,6 +400,10 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": round(kern_ms, 4),
+                # what the fraction is short of (measured): neither memory nor the matrix pipe alone
+                "limiter": ("issue slots: one wave per SIMD issues 384 MFMAs and ~370 other instructions per 64-row tile "
+                            "(24 LDS-DMA pieces of 45-50 cycles each), at the 1.5-1.9 GHz the board's power limit leaves"
+                            if kernel_name == "cosine_topk_walk_kernel" else None),
                 "mfma_tflops": round(flops / (kern_ms * 1e-3) / 1e12, 1),
                 "mfma_frac": round(flops / (kern_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
                 "peaks_vendor": {"hbm_GBps": HBM_PEAK_GBS, "mfma_f16_TFLOPs": MFMA_F16_PEAK_TFLOPS},
