@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void mfma_peak16_kernel(const half8_t *__restr
 // over 16 fragments (64 registers) of the accumulator file; 3: (2) + the statement's v_xad and two ds_read_b128 of the
 // NEXT statement's A fragments; 4: (3) + the closing s_waitcnt lgkmcnt(0); 5: (4) + one 1 KiB LDS-DMA piece after every
 // other statement (per-lane offsets, the walk's form), 6: the same piece without a per-lane offset (timing only),
-// 7: as 5 with the two pieces of an iteration back to back.  stamps[2 wg] = shader cycles (s_memtime),
+// 7: as 5 with the two pieces of an iteration back to back; 8: the statement of 4 with its fillers spread over the MFMA
+// gaps; 9: as 5 with global_load_lds_dwordx4 instead of buffer_load ... lds.  stamps[2 wg] = shader cycles (s_memtime),
 // stamps[2 wg + 1] = 100 MHz ticks (s_memrealtime) of wave 0's loop.
 #define MMRAG_PROBE_8(QC, Q0, Q1, Q2, Q3, PRE, POST)                                                                  \
     asm volatile(PRE "v_mfma_f32_16x16x32_f16 %[d0], %[a0], %[" Q0 "], %[d0]\n\t"                                     \
@@ -181,7 +182,10 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const half8_t *__res
     auto piece = [&](int it, int h) {
         typedef __attribute__((address_space(3))) void *lds_t;
         char *dst = (char *)tile + 32768 + (threadIdx.x >> 6) * 8192 + (((it << 1) + h) & 7) * 1024;
-        if constexpr (MODE == 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t)dst, 16, 0, (h + (it & 1) * 2) * 1024, 0, 2);
+        if constexpr (MODE == 9)   // the same piece as a global (not buffer) LDS-DMA load: per-lane 64-bit addresses
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)seed + voff + (h + (it & 1) * 2) * 1024),
+                                             (lds_t)dst, 16, 0, 2);
+        else if constexpr (MODE == 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t)dst, 16, 0, (h + (it & 1) * 2) * 1024, 0, 2);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t)dst, 16, voff, (h + (it & 1) * 2) * 1024, 0, 2);
     };
     const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
@@ -190,14 +194,14 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const half8_t *__res
         constexpr int R = MODE >= 2 ? 4 : 0;   // B fragments rotate over q[0..15] / stay q[0..3]
         probe_stmt<MODE>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], a0, a1, q[0], q[1], q[2], q[3], b0, b1, lo, st);
         probe_stmt<MODE>(c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], b0, b1, q[R], q[R + 1], q[R + 2], q[R + 3], a0, a1, lo, st + 1024);
-        if constexpr (MODE == 5 || MODE == 6) piece(it, 0);
+        if constexpr (MODE == 5 || MODE == 6 || MODE == 9) piece(it, 0);
         probe_stmt<MODE>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], a0, a1, q[2 * R], q[2 * R + 1], q[2 * R + 2], q[2 * R + 3], b0, b1, lo, st + 2048);
         probe_stmt<MODE>(c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], b0, b1, q[3 * R], q[3 * R + 1], q[3 * R + 2], q[3 * R + 3], a0, a1, lo, st + 3072);
-        if constexpr (MODE >= 5 && MODE <= 7) piece(it, 1);
+        if constexpr ((MODE >= 5 && MODE <= 7) || MODE == 9) piece(it, 1);
         if constexpr (MODE == 7) piece(it, 0);
-        if constexpr (MODE >= 5 && MODE <= 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr ((MODE >= 5 && MODE <= 7) || MODE == 9) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
-    if constexpr (MODE >= 5 && MODE <= 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr ((MODE >= 5 && MODE <= 7) || MODE == 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_nop 15\n\ts_nop 7");
     f32x4_t t = c[0];
@@ -271,7 +275,7 @@ int mmrag_bench_mfma_f16(const void *seed, float *out, int iters, int64_t *flops
 
 // developer probe (tools/mfma_probe.py): 32 MFMAs per iteration and wave; not part of the reference-facing surface
 int mmrag_internal_mfma_probe(const void *seed, float *out, int iters, int mode, long long *stamps, void *stream) {
-    MMRAG_CHECK_ARG(seed && out && iters > 0 && mode >= 0 && mode <= 8, "mfma_probe: bad arguments");
+    MMRAG_CHECK_ARG(seed && out && iters > 0 && mode >= 0 && mode <= 9, "mfma_probe: bad arguments");
     const int grid = num_cus();
     hipStream_t s = (hipStream_t)stream;
     switch (mode) {
@@ -283,7 +287,8 @@ int mmrag_internal_mfma_probe(const void *seed, float *out, int iters, int mode,
     case 5: mfma_probe_kernel<5><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
     case 6: mfma_probe_kernel<6><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
     case 7: mfma_probe_kernel<7><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
-    default: mfma_probe_kernel<8><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    case 8: mfma_probe_kernel<8><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
+    default: mfma_probe_kernel<9><<<grid, 256, 0, s>>>((const half8_t *)seed, out, iters, stamps); break;
     }
     MMRAG_CHECK_HIP(hipGetLastError());
     return MMRAG_OK;

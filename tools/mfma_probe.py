@@ -12,10 +12,10 @@ out = torch.empty(ncu * 256, device="cuda"); stamps = torch.zeros(ncu * 2, dtype
 iters = 20000
 names = ["A,B in VGPRs", "B in AGPRs", "B rotating over 64 AGPRs", "+ v_xad + 2 ds_read_b128 / 8 MFMAs", "+ s_waitcnt lgkmcnt(0)",
          "+ one LDS-DMA piece / 16 MFMAs (per-lane offsets)", "+ one LDS-DMA piece / 16 MFMAs (no per-lane offset)",
-         "+ two LDS-DMA pieces back to back / 32 MFMAs", "mode 4 with its fillers spread over the MFMA gaps"]
+         "+ two LDS-DMA pieces back to back / 32 MFMAs", "mode 4 with its fillers spread over the MFMA gaps", "+ one global_load_lds piece / 16 MFMAs"]
 st = torch.cuda.current_stream().cuda_stream
 for rnd in range(2):
-    for mode in range(9):
+    for mode in range(10):
         for _ in range(int(os.environ.get("HOLD", "200"))):
             rc = L.mmrag_internal_mfma_probe(seed.data_ptr(), out.data_ptr(), iters, mode, stamps.data_ptr(), st); assert rc == 0
         torch.cuda.synchronize()
